@@ -1,0 +1,397 @@
+// fs_abi.hip - host side of libflowsim_hip.so: the C ABI declared in include/flowsim_abi.h.
+//
+// Owns the device buffers of a batch (SoA, reach-major state [B][N]; per-level tables [level][B]),
+// converts caller float64 host arrays to the batch dtype on upload, picks the kernel instantiation
+// (cells per lane M, waves per reach W) from N, and launches the fused step kernel on the
+// handle's HIP stream.  No CPU compute path exists here: without a HIP device every entry point
+// that needs one fails and says so.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fs_kernel.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const std::string &m) { g_err = m; return -1; }
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_));   \
+  } while (0)
+
+struct Shape { int M, W; };
+
+typedef void (*LaunchFn)(const void *args, int B, hipStream_t st);
+typedef const void *KernelPtr;
+
+template <typename R, int SEC, int M, int W> void launch_(const void *args, int B, hipStream_t st) {
+  const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W>), dim3(B), dim3(64 * W), 0, st, a);
+}
+
+struct Entry { int dtype, sec, M, W; LaunchFn fn; KernelPtr kp; };
+
+#define FS_ENTRY(R, DT, SEC, M, W) \
+  { DT, SEC, M, W, &launch_<R, SEC, M, W>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W> }
+
+#define FS_ENTRIES(R, DT)                                                                         \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 2, 1),          \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),          \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 2),        \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
+  FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
+  FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
+  FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
+
+const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32)};
+
+const Entry *pick_kernel(int dtype, int sec, int N, std::string *why) {
+  const int cells = N - 1;
+  int wantM = 0, wantW = 0;
+  if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
+  const Entry *best = nullptr;
+  for (const Entry &e : kEntries) {
+    if (e.dtype != dtype || e.sec != sec) continue;
+    if (64 * e.W * e.M < cells) continue;
+    if (wantM && (e.M != wantM || e.W != wantW)) continue;
+    // smallest capacity first; on ties prefer fewer waves per reach (less cross-wave work)
+    if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W)) best = &e;
+  }
+  if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4097 nodes)";
+  return best;
+}
+
+}  // namespace
+
+struct fs_batch {
+  fs_batch_desc d;
+  size_t esz;                 // sizeof(real)
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timed = false;
+  int launches = 0;
+  int level = 0;
+  const Entry *kern = nullptr;
+  // scheme
+  double theta = 0.6, dt = 0, dx = 0, tol = 1e-4;
+  int max_iter = 100;
+  bool have_scheme = false, have_geo = false, have_state = false, have_bc[2] = {false, false};
+  // device buffers
+  void *hk = nullptr, *Qk = nullptr, *hg = nullptr, *Qg = nullptr;
+  void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
+  void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
+  int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
+  void *Yprev = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
+  int32_t *iters = nullptr, *status = nullptr;
+};
+
+namespace {
+
+int upload(fs_batch *b, void **dst, const double *src, size_t n) {
+  if (!*dst) HIP_TRY(hipMalloc(dst, n * b->esz));
+  if (b->d.dtype == FS_F64) {
+    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  } else {
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+    HIP_TRY(hipMemcpyAsync(*dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  return 0;
+}
+
+int download(fs_batch *b, double *dst, const void *src, size_t off_elems, size_t n) {
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (b->d.dtype == FS_F64) {
+    HIP_TRY(hipMemcpy(dst, (const char *)src + off_elems * 8, n * 8, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<float> tmp(n);
+    HIP_TRY(hipMemcpy(tmp.data(), (const char *)src + off_elems * 4, n * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+  }
+  return 0;
+}
+
+template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelArgs<R> &a) {
+  a.B = b->d.n_reaches; a.N = b->d.n_nodes; a.n_steps = n_steps; a.level0 = b->level; a.max_iter = b->max_iter;
+  a.theta = (R)b->theta; a.dt = (R)b->dt; a.dx = (R)b->dx; a.tol = (R)b->tol;
+  a.hk = (R *)b->hk; a.Qk = (R *)b->Qk; a.hg = (R *)b->hg; a.Qg = (R *)b->Qg;
+  a.geo_uniform = (const R *)b->geo_uniform; a.geo_table = (const R *)b->geo_table;
+  a.n_override = (const R *)b->n_override;
+  fs::BCDesc<R> *bc[2] = {&a.us, &a.ds};
+  for (int s = 0; s < 2; ++s) {
+    bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
+    bc[s]->params = (const R *)b->bc_params[s]; bc[s]->target = (const R *)b->bc_target[s];
+  }
+  a.Yprev = (R *)b->Yprev; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
+  a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fs_abi_version(void) { return FS_ABI_VERSION; }
+
+int fs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *fs_last_error(void) { return g_err.c_str(); }
+
+fs_batch *fs_batch_create(const fs_batch_desc *desc) {
+  if (!desc) { fail("fs_batch_create: null descriptor"); return nullptr; }
+  if (desc->n_reaches < 1 || desc->n_nodes < 2 || desc->max_levels < 2) {
+    fail("fs_batch_create: need n_reaches >= 1, n_nodes >= 2, max_levels >= 2"); return nullptr;
+  }
+  if (desc->dtype != FS_F64 && desc->dtype != FS_F32) { fail("fs_batch_create: bad dtype"); return nullptr; }
+  if (desc->section_mode != FS_SEC_RECT_UNIFORM && desc->section_mode != FS_SEC_TABLE) {
+    fail("fs_batch_create: bad section_mode"); return nullptr;
+  }
+  if (fs_device_count() <= desc->device || desc->device < 0) {
+    fail("fs_batch_create: no HIP device " + std::to_string(desc->device) +
+         " (this library has no CPU path; it needs an MI355X)");
+    return nullptr;
+  }
+  std::string why;
+  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, &why);
+  if (!k) { fail("fs_batch_create: " + why); return nullptr; }
+  fs_batch *b = new fs_batch();
+  b->d = *desc;
+  b->esz = desc->dtype == FS_F64 ? 8 : 4;
+  b->kern = k;
+  auto bad = [&](const char *what, hipError_t e) {
+    fail(std::string("fs_batch_create: ") + what + ": " + hipGetErrorString(e));
+    fs_batch_destroy(b);
+    return (fs_batch *)nullptr;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(desc->device)) != hipSuccess) return bad("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return bad("hipStreamCreate", e);
+  if ((e = hipEventCreate(&b->ev0)) != hipSuccess) return bad("hipEventCreate", e);
+  if ((e = hipEventCreate(&b->ev1)) != hipSuccess) return bad("hipEventCreate", e);
+  const size_t B = desc->n_reaches, N = desc->n_nodes, L = desc->max_levels;
+  void **state[4] = {&b->hk, &b->Qk, &b->hg, &b->Qg};
+  for (void **p : state)
+    if ((e = hipMalloc(p, B * N * b->esz)) != hipSuccess) return bad("hipMalloc(state)", e);
+  if ((e = hipMalloc(&b->hydro, L * 4 * B * b->esz)) != hipSuccess) return bad("hipMalloc(hydro)", e);
+  if ((e = hipMalloc((void **)&b->iters, L * B * 4)) != hipSuccess) return bad("hipMalloc(iters)", e);
+  if ((e = hipMalloc((void **)&b->status, B * 4)) != hipSuccess) return bad("hipMalloc(status)", e);
+  if ((e = hipMalloc(&b->Yprev, B * b->esz)) != hipSuccess) return bad("hipMalloc(Yprev)", e);
+  if (desc->flags & FS_FLAG_HISTORY) {
+    if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
+    if ((e = hipMalloc(&b->hist_Q, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
+  }
+  hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
+  hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);
+  hipMemsetAsync(b->status, 0, B * 4, b->stream);
+  hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream);
+  hipStreamSynchronize(b->stream);
+  return b;
+}
+
+void fs_batch_destroy(fs_batch *b) {
+  if (!b) return;
+  if (b->stream) hipStreamSynchronize(b->stream);
+  void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
+                  b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->hydro, b->hist_h, b->hist_Q,
+                  b->iters, b->status};
+  for (void *p : bufs) if (p) hipFree(p);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double tolerance, int32_t max_iter) {
+  if (!b) return fail("null handle");
+  if (!(dt > 0) || !(dx > 0) || !(tolerance > 0) || max_iter < 1) return fail("fs_batch_set_scheme: dt, dx, tolerance > 0 and max_iter >= 1 required");
+  b->theta = theta; b->dt = dt; b->dx = dx; b->tol = tolerance; b->max_iter = max_iter;
+  b->have_scheme = true;
+  return 0;
+}
+
+int fs_batch_set_geometry_uniform(fs_batch *b, const double *params) {
+  if (!b || !params) return fail("fs_batch_set_geometry_uniform: null argument");
+  if (b->d.section_mode != FS_SEC_RECT_UNIFORM) return fail("fs_batch_set_geometry_uniform: batch was created with another section_mode");
+  const size_t B = b->d.n_reaches;
+  for (size_t i = 0; i < B; ++i)
+    if (!(params[FS_RU_WIDTH * B + i] > 0) || !(params[FS_RU_MANNING * B + i] > 0))
+      return fail("fs_batch_set_geometry_uniform: width and Manning n must be positive");
+  if (upload(b, &b->geo_uniform, params, (size_t)FS_RU_NPARAM * B)) return -1;
+  b->have_geo = true;
+  return 0;
+}
+
+int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *n_main_override) {
+  if (!b || !table) return fail("fs_batch_set_geometry_table: null argument");
+  if (b->d.section_mode != FS_SEC_TABLE) return fail("fs_batch_set_geometry_table: batch was created with another section_mode");
+  if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * b->d.n_nodes)) return -1;
+  if (n_main_override) {
+    if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
+  } else if (b->n_override) {
+    hipFree(b->n_override); b->n_override = nullptr;
+  }
+  b->have_geo = true;
+  return 0;
+}
+
+int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *params, int32_t n_params,
+                    int32_t per_reach, const double *target) {
+  if (!b) return fail("null handle");
+  if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: side must be FS_UPSTREAM or FS_DOWNSTREAM");
+  static const int need[] = {0, 1, 1, 2, 4, 5, 10, 5};
+  if (kind < 0 || kind > FS_BC_STORAGE) return fail("Invalid boundary condition.");              // boundary.py:33
+  if (n_params != need[kind]) return fail("Insufficient arguments for boundary condition.");      // boundary.py:83
+  if (n_params > 0 && !params) return fail("Insufficient arguments for boundary condition.");
+  if ((kind == FS_BC_FLOW_HYDROGRAPH || kind == FS_BC_STAGE_HYDROGRAPH) && !target)
+    return fail("Insufficient arguments for boundary condition.");                                // boundary.py:87
+  if (kind == FS_BC_STORAGE && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
+  const size_t B = b->d.n_reaches;
+  if (b->bc_params[side]) { hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
+  if (b->bc_target[side]) { hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
+  if (n_params > 0 && upload(b, &b->bc_params[side], params, per_reach ? n_params * B : (size_t)n_params)) return -1;
+  if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
+  b->bc_kind[side] = kind; b->bc_stride[side] = per_reach ? 1 : 0;
+  b->have_bc[side] = true;
+  return 0;
+}
+
+int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
+  if (!b || !h || !Q) return fail("fs_batch_set_state: null argument");
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes;
+  if (upload(b, &b->hk, h, B * N) || upload(b, &b->Qk, Q, B * N) || upload(b, &b->hg, h, B * N) || upload(b, &b->Qg, Q, B * N)) return -1;
+  if (b->hist_h) {   // level 0 of the history = initial conditions (solver.py:61-63)
+    void *p = b->hist_h, *q = b->hist_Q;
+    if (upload(b, &p, h, B * N) || upload(b, &q, Q, B * N)) return -1;
+  }
+  std::vector<double> row(4 * B);
+  for (size_t r = 0; r < B; ++r) {
+    row[0 * B + r] = h[r * N]; row[1 * B + r] = Q[r * N];
+    row[2 * B + r] = h[r * N + N - 1]; row[3 * B + r] = Q[r * N + N - 1];
+  }
+  void *p = b->hydro;
+  if (upload(b, &p, row.data(), 4 * B)) return -1;
+  HIP_TRY(hipMemsetAsync(b->status, 0, B * 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
+  b->level = 0;
+  b->have_state = true;
+  return 0;
+}
+
+int fs_batch_step(fs_batch *b, int32_t n_steps) {
+  if (!b) return fail("null handle");
+  if (!b->have_scheme || !b->have_geo || !b->have_state || !b->have_bc[0] || !b->have_bc[1])
+    return fail("fs_batch_step: scheme, geometry, both boundaries and the initial state must be set first");
+  if (n_steps < 1) return fail("fs_batch_step: n_steps must be >= 1");
+  if (b->level + n_steps >= b->d.max_levels) return fail("fs_batch_step: would run past max_levels");
+  HIP_TRY(hipSetDevice(b->d.device));
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  if (b->d.dtype == FS_F64) {
+    fs::KernelArgs<double> a; fill_args(b, n_steps, a);
+    b->kern->fn(&a, b->d.n_reaches, b->stream);
+  } else {
+    fs::KernelArgs<float> a; fill_args(b, n_steps, a);
+    b->kern->fn(&a, b->d.n_reaches, b->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  b->timed = true; b->launches = 1;
+  b->level += n_steps;
+  return 0;
+}
+
+int fs_batch_sync(fs_batch *b) {
+  if (!b) return fail("null handle");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return 0;
+}
+
+int32_t fs_batch_level(const fs_batch *b) { return b ? b->level : -1; }
+
+int fs_batch_get_state(fs_batch *b, double *h, double *Q) {
+  if (!b || !h || !Q) return fail("fs_batch_get_state: null argument");
+  const size_t n = (size_t)b->d.n_reaches * b->d.n_nodes;
+  return download(b, h, b->hk, 0, n) || download(b, Q, b->Qk, 0, n) ? -1 : 0;
+}
+
+int fs_batch_get_guess(fs_batch *b, double *h, double *Q) {
+  if (!b || !h || !Q) return fail("fs_batch_get_guess: null argument");
+  const size_t n = (size_t)b->d.n_reaches * b->d.n_nodes;
+  return download(b, h, b->hg, 0, n) || download(b, Q, b->Qg, 0, n) ? -1 : 0;
+}
+
+int fs_batch_get_hydrographs(fs_batch *b, int32_t first, int32_t n, double *out) {
+  if (!b || !out) return fail("fs_batch_get_hydrographs: null argument");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_hydrographs: level range out of bounds");
+  const size_t B = b->d.n_reaches;
+  return download(b, out, b->hydro, (size_t)first * 4 * B, (size_t)n * 4 * B);
+}
+
+int fs_batch_get_iterations(fs_batch *b, int32_t first, int32_t n, int32_t *out) {
+  if (!b || !out) return fail("fs_batch_get_iterations: null argument");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_iterations: level range out of bounds");
+  const size_t B = b->d.n_reaches;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->iters + (size_t)first * B, (size_t)n * B * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fs_batch_get_status(fs_batch *b, int32_t *out) {
+  if (!b || !out) return fail("fs_batch_get_status: null argument");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->status, (size_t)b->d.n_reaches * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, double *Q) {
+  if (!b || !h || !Q) return fail("fs_batch_get_history: null argument");
+  if (!b->hist_h) return fail("fs_batch_get_history: batch was created without FS_FLAG_HISTORY");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_history: level range out of bounds");
+  const size_t per = (size_t)b->d.n_reaches * b->d.n_nodes;
+  return download(b, h, b->hist_h, first * per, n * per) || download(b, Q, b->hist_Q, first * per, n * per) ? -1 : 0;
+}
+
+int fs_batch_get_storage_stage(fs_batch *b, double *out) {
+  if (!b || !out) return fail("fs_batch_get_storage_stage: null argument");
+  return download(b, out, b->Yprev, 0, b->d.n_reaches);
+}
+
+void *fs_batch_hydrograph_device_ptr(fs_batch *b) { return b ? b->hydro : nullptr; }
+void *fs_batch_stream(fs_batch *b) { return b ? (void *)b->stream : nullptr; }
+
+double fs_batch_last_step_ms(fs_batch *b) {
+  if (!b || !b->timed) return -1.0;
+  float ms = 0.f;
+  if (hipEventSynchronize(b->ev1) != hipSuccess) return -1.0;
+  if (hipEventElapsedTime(&ms, b->ev0, b->ev1) != hipSuccess) return -1.0;
+  return (double)ms;
+}
+
+int32_t fs_batch_last_launch_count(fs_batch *b) { return b ? b->launches : 0; }
+
+int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach, int32_t *lds_bytes,
+                         int32_t *vgprs) {
+  if (!b) return fail("null handle");
+  hipFuncAttributes at;
+  HIP_TRY(hipFuncGetAttributes(&at, b->kern->kp));
+  if (cells_per_thread) *cells_per_thread = b->kern->M;
+  if (waves_per_reach) *waves_per_reach = b->kern->W;
+  if (lds_bytes) *lds_bytes = (int32_t)at.sharedSizeBytes;
+  if (vgprs) *vgprs = at.numRegs;
+  return 0;
+}
+
+}  // extern "C"

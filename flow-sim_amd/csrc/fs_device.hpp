@@ -1,0 +1,369 @@
+// fs_device.hpp - device-side hydraulics and the 2x2-block segment algebra for gfx950.
+//
+// Everything here is per-lane scalar code: the Preissmann system is a banded recurrence, there is
+// no dense contraction to hand to MFMA.  The expensive scalar ops (fp64 divide, x^(2/3)) are
+// replaced by v_rcp_f64 / v_log_f32+v_exp_f32 seeds refined with FMAs.
+//
+// Reference formulas (cve-mohd/flow-sim): src/hydromodel/hydraulics.py:4-229,
+// cross_section.py:114-175,:623-793, boundary.py:56-242, rating_curve.py:32-63,:132-147,
+// lumped_storage.py:24-45.  Bug-compatibility notes refer to SURVEY.md section 0 (F2, F3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/flowsim_abi.h"
+
+namespace fs {
+
+constexpr double kG = 9.80665;  // scipy.constants.g (hydraulics.py:2)
+
+// ---------------------------------------------------------------------------------------------
+// scalar helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double frcp(double x) {
+  // v_rcp_f64 seed + two Newton steps: ~1 ulp for normal, finite x (all our operands)
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ float frcp(float x) {
+  float r = __builtin_amdgcn_rcpf(x);
+  float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(r, e, r);
+}
+
+// x^(-1/3) for x > 0
+__device__ __forceinline__ double rcbrt_pos(double x) {
+  float xf = (float)x;
+  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // Newton on y^-3 = x : y += y*(1 - x y^3)/3
+    double t = y * y;
+    double e = __builtin_fma(-(x * t), y, 1.0);
+    y = __builtin_fma(y * (1.0 / 3.0), e, y);
+  }
+  return y;
+}
+__device__ __forceinline__ float rcbrt_pos(float x) {
+  float y = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (-1.0f / 3.0f));
+  float t = y * y;
+  float e = __builtin_fmaf(-(x * t), y, 1.0f);
+  return __builtin_fmaf(y * (1.0f / 3.0f), e, y);
+}
+
+template <typename R> __device__ __forceinline__ R fabs_(R x) { return x < R(0) ? -x : x; }
+template <typename R> __device__ __forceinline__ R fmax_(R a, R b) { return a > b ? a : b; }
+__device__ __forceinline__ double pow_(double a, double b) { return pow(a, b); }
+__device__ __forceinline__ float pow_(float a, float b) { return powf(a, b); }
+__device__ __forceinline__ double sqrt_(double a) { return sqrt(a); }
+__device__ __forceinline__ float sqrt_(float a) { return sqrtf(a); }
+
+// ---------------------------------------------------------------------------------------------
+// node terms: everything the residual / Jacobian needs from one node at state (h, Q)
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct NodeTerms {
+  R A;    // wetted area                         (cross_section.py:623-679)
+  R T;    // dA/dh = top width                   (cross_section.py:792-793)
+  R Se;   // Sf + Sc                             (channel.py:53-69)
+  R eA;   // (dSe/dA in the reference's mixed convention) * dA/dh      (channel.py:71-87)
+  R eQ;   // dSe/dQ                              (channel.py:89-105)
+  R v;    // Q / A
+};
+
+// trapezoidal section parameters at one node (cross_section.py:569-613)
+template <typename R> struct SecParams {
+  R z, b, m, nm, nl, nr, hbf, bl, br, mfp, curv;
+  bool compound;
+};
+
+// Rectangular prismatic fast path: A = b h, P = b + 2h, T = b (cross_section.py:636-639).
+// dK/dA / K reduces algebraically to (1 + (2/3) b / P) / A for a rectangle (cross_section.py:756-790
+// with hydraulics.py:28-40), so one reciprocal of P*h and one x^(-1/3) serve the whole node.
+template <typename R>
+__device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q) {
+  NodeTerms<R> t;
+  const R A = b * h;
+  const R P = __builtin_fma(R(2), h, b);
+  const R r = frcp(P * h);
+  const R rP = r * h, rh = r * P;
+  const R Rh = A * rP;                   // hydraulic radius
+  const R rA = rh * rb;                  // 1/A
+  const R y = rcbrt_pos(Rh);             // R^(-1/3);  K = A R^(2/3)/n  ->  1/K^2 = (n y^2 / A)^2
+  const R nk = n * rA * (y * y);
+  const R iK2 = nk * nk;
+  const R aQ = fabs_(Q);
+  t.A = A;
+  t.T = b;
+  t.Se = Q * aQ * iK2;                                             // hydraulics.py:57
+  t.eQ = R(2) * aQ * iK2;                                          // hydraulics.py:92
+  t.eA = R(-2) * t.Se * __builtin_fma(R(2.0 / 3.0) * b, rP, R(1)) * rh;  // hydraulics.py:75 times T
+  t.v = Q * rA;
+  return t;
+}
+
+// conveyance of a single sub-section, hydraulics.py:15-26
+template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * pow_(Rh, R(2.0 / 3.0)) / n; }
+
+template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA; };
+
+// General trapezoid family (rectangle / simple / compound), straight from the reference including
+// the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
+// pow()-heavy and only the boundary rows and the TABLE geometry mode use it.
+template <typename R>
+__device__ __noinline__ GeneralProps<R> general_props(const SecParams<R> s, R h) {
+  GeneralProps<R> g;
+  const R d = fmax_(R(0), h);
+  const R sm = sqrt_(R(1) + s.m * s.m);
+  R T = s.b + R(2) * s.m * d;
+  R A = (s.b + T) / R(2) * d;
+  R P = s.b + R(2) * d * sm;
+  R dPdh = R(2) * sm;
+  const bool over = s.compound && d > s.hbf;
+  R K;
+  if (over) {
+    const R dfp = d - s.hbf;
+    const R Tb = s.b + R(2) * s.m * s.hbf;
+    const R sfp = sqrt_(R(1) + s.mfp * s.mfp);
+    const R A_main = (s.b + Tb) / R(2) * s.hbf;                  // :660 (column above omitted)
+    const R P_main = s.b + R(2) * s.hbf * sm;
+    const R A_l = (s.bl + R(0.5) * s.mfp * dfp) * dfp, P_l = s.bl + dfp * sfp;
+    const R A_r = (s.br + R(0.5) * s.mfp * dfp) * dfp, P_r = s.br + dfp * sfp;
+    A = A_main + A_l + A_r;
+    P = P_main + P_l + P_r;
+    T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
+    dPdh = R(2) * sfp;
+    const R A_m = A_main + Tb * dfp;                             // :694 (column included)
+    const R R_m = P_main > R(0) ? A_m / P_main : R(0);
+    const R R_l = P_l > R(0) ? A_l / P_l : R(0);
+    const R R_r = P_r > R(0) ? A_r / P_r : R(0);
+    const R Kl = conv_(A_l, s.nl, R_l), Km = conv_(A_m, s.nm, R_m), Kr = conv_(A_r, s.nr, R_r);
+    K = pow_(pow_(Kl, R(1.5)) + pow_(Km, R(1.5)) + pow_(Kr, R(1.5)), R(2.0 / 3.0));   // :753
+    g.Rh = P > R(0) ? A / P : R(0);
+  } else {
+    g.Rh = P > R(0) ? A / P : R(0);
+    K = conv_(A, s.nm, g.Rh);
+    if (s.compound) K = pow_(pow_(K, R(1.5)), R(2.0 / 3.0));     // the reference's round trip, :747-754
+  }
+  const R R23 = pow_(g.Rh, R(2.0 / 3.0));
+  R neq = s.nm;
+  if (s.compound && A > R(0) && g.Rh > R(0) && K > R(0)) neq = A * R23 / K;     // :710-739
+  g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * (R(1) / T))) / (P * P);   // :766-790
+  g.dKdA = A <= R(0) ? R(0)
+                     : (R23 + A * R(2.0 / 3.0) * pow_(g.Rh, R(2.0 / 3.0 - 1.0)) * g.dRdA) / neq;  // :756-764
+  g.A = A; g.P = P; g.T = T; g.K = K; g.neq = neq;
+  return g;
+}
+
+template <typename R>
+__device__ __noinline__ NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
+  const GeneralProps<R> g = general_props(s, h);
+  NodeTerms<R> t;
+  const R iK2 = R(1) / (g.K * g.K);
+  const R aQ = fabs_(Q);
+  const R Sf = Q * aQ * iK2;
+  R dSeA = R(-2) * Sf * (g.dKdA / g.K);   // per unit area
+  R Se = Sf, eQ = R(2) * aQ * iK2;
+  if (s.curv != R(0)) {                   // ==0 guard for Sc, <=1e-12 guard for its derivatives
+    const R A = g.A, T = g.T, Rh = g.Rh;
+    const R rc = R(1) / s.curv;
+    const R V = Q / fmax_(A, R(1e-6));                            // hydraulics.py:155-168
+    const R D = A / fmax_(T, R(1e-6));
+    const R Fr = V / sqrt_(R(kG) * fmax_(D, R(1e-6)));
+    const R C = pow_(Rh, R(1.0 / 6.0)) / g.neq;
+    const R f = R(8) * R(kG) / (C * C);                           // :217-229
+    const R sq = sqrt_(f);
+    const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
+    const R den = (R(0.565) + sq) * rc * rc;
+    Se = Sf + num / den;                                          // :94-117
+    if (fabs_(s.curv) > R(1e-12)) {
+      const R gD = R(kG) * (A / T);
+      const R Vr = Q / A;
+      const R dFrA = R(-0.5) * Vr * pow_(gD, R(-1.5)) * R(kG) * (R(1) / T) + (-Q / (A * A)) * pow_(gD, R(-0.5));
+      const R dfA = -(R(8.0 / 3.0)) * R(kG) * g.neq * g.neq * pow_(Rh, R(-4.0 / 3.0)) * g.dRdA;
+      const R dnum = (R(2.86) / (R(2) * sq) * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
+                     (R(2.86) * sq + R(2.07) * f) * (R(2) * h * (R(1) / T) * Fr * Fr + h * h * R(2) * Fr * dFrA);
+      const R dden = (R(1) / (R(2) * sq) * dfA) * rc * rc;
+      dSeA += (dnum * den - num * dden) / (den * den) * T;        // :119-137, x dA_dh (cross_section.py:164)
+      const R dFrQ = (R(1) / A) * pow_(gD, R(-0.5));
+      const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
+      eQ += (dnumq * den) / (den * den);                          // :139-153
+    }
+  }
+  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q / g.A;
+  return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// boundary rows  (boundary.py:56-242)
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct BCDesc {
+  int32_t kind;
+  int32_t stride;          // 0: params shared by all reaches, 1: params[i*B + reach]
+  const R *params;
+  const R *target;         // [levels][B] or nullptr
+};
+template <typename R> struct BCRow { R dh, dq, res; };   // dh*d(h) + dq*d(Q) = -res
+
+template <typename R>
+__device__ __forceinline__ R bc_param(const BCDesc<R> &bc, int i, int reach, int B) {
+  return bc.stride ? bc.params[(size_t)i * B + reach] : bc.params[i];
+}
+
+template <typename R>
+__device__ __forceinline__ R rating_blend(R z, R s0, R buf, R l0, R l1, R l2, R h0, R h1, R h2) {
+  R al;
+  if (z >= s0 + buf) al = R(1);
+  else if (z <= s0) al = R(0);
+  else { const R s = (z - s0) / buf; al = R(3) * s * s - R(2) * s * s * s; }
+  const R lo = l0 + l1 * z + l2 * z * z;
+  const R hi = h0 + h1 * z + h2 * z * z;
+  return (R(1) - al) * lo + al * hi;
+}
+
+// sec: section of the boundary node; Qold: flow[k-1] at that node; Yprev: storage stage of level
+// k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).
+template <typename R>
+__device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int level, const SecParams<R> sec,
+                                         R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
+  BCRow<R> r;
+  auto p = [&](int i) { return bc_param(bc, i, reach, B); };
+  switch (bc.kind) {
+    case FS_BC_FLOW_HYDROGRAPH:
+      r.res = Q - bc.target[(size_t)level * B + reach]; r.dh = R(0); r.dq = R(1); break;
+    case FS_BC_STAGE_HYDROGRAPH:
+      r.res = h - (bc.target[(size_t)level * B + reach] - p(0)); r.dh = R(1); r.dq = R(0); break;
+    case FS_BC_FIXED_DEPTH:
+      r.res = h - p(0); r.dh = R(1); r.dq = R(0); break;
+    case FS_BC_NORMAL_DEPTH: {
+      const R S0 = p(0), bed = p(1);
+      const R sg = S0 < R(0) ? R(-1) : R(1);
+      const R rt = sqrt_(fabs_(S0));
+      const GeneralProps<R> gr = general_props(sec, h);                 // residual: hw = z_min + h
+      const GeneralProps<R> gd = general_props(sec, h + bed - sec.z);   // df_dh: hw = h + bed_level
+      r.res = Q - sg * gr.K * rt;                                       // hydraulics.py:4-13
+      r.dh = R(0) - sg * gd.dKdA * rt * gd.T;                           // hydraulics.py:206-215
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_POWER: {
+      const R x = p(3) + h + p(2);
+      r.res = Q - p(0) * pow_(x, p(1));
+      r.dh = R(0) - p(0) * p(1) * pow_(x, p(1) - R(1));
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_POLY: {
+      const R x = p(4) + h + p(3);
+      r.res = Q - (p(0) * x * x + p(1) * x + p(2));
+      r.dh = R(0) - (p(0) * R(2) * x + p(1));
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_BLEND: {
+      const R z = p(9) + h, dY = p(8);
+      const R q0 = rating_blend(z, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      const R qp = rating_blend(z + dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      const R qm = rating_blend(z - dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      r.res = Q - q0;
+      r.dh = R(0) - (qp - qm) / (R(2) * dY);                            // roseires_rating_curve.py:202-208
+      r.dq = R(1);
+    } break;
+    case FS_BC_STORAGE: {
+      const R area = p(0), ymin = p(1), bed = p(4);
+      const R vol = R(0.5) * (Qold + Q) * dt;                           // preissmann.py:314
+      const R Yold = level == 1 ? h + bed : Yprev;                      // boundary.py:104-108 (k==1 quirk)
+      R Y = Yold + vol / area;                                          // root of lumped_storage.py:25-28
+      if (!(Y >= p(2) && Y <= p(3))) *flag = FS_STORAGE_RANGE;          // brentq would raise
+      if (Y < ymin) Y = ymin;
+      *Ynew = Y;
+      r.res = h - (Y - bed);
+      r.dh = R(1);
+      r.dq = R(0) - (Y <= ymin ? R(0) : R(1) / area) * R(0.5) * dt;     // boundary.py:213-237
+    } break;
+    default:
+      r.res = R(0); r.dh = R(1); r.dq = R(0); break;
+  }
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// segment algebra: a "segment" is the pair of linear relations left between the first and the
+// last node of a run of cells once the interior nodes are eliminated,
+//     C-like row:  pc . d_first + sc . d_last = qc
+//     M-like row:  pm . d_first + sm . d_last = qm          (d = (dh, dQ))
+// A single cell is a segment (rows = continuity, momentum).  merge() eliminates the node shared by
+// two adjacent segments, pivoting on (M-like row of the left, C-like row of the right): the block
+// row order of the classical Preissmann double sweep, stable for sub-critical flow without
+// pivoting (checked against SuperLU in tests/test_partition_model.py).
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct Seg { R pc0, pc1, sc0, sc1, qc, pm0, pm1, sm0, sm1, qm; };
+// what is needed to recover the eliminated node from the two outer ones
+template <typename R> struct Elim { R w10, w11, w20, w21, pm0, pm1, qm, sc0, sc1, qc; };
+
+template <typename R>
+__device__ __forceinline__ void merge(const Seg<R> &A, const Seg<R> &B, Seg<R> &O, Elim<R> &e) {
+  const R det = A.sm0 * B.pc1 - A.sm1 * B.pc0;
+  const R r = frcp(det);
+  const R w10 = B.pc1 * r, w11 = -B.pc0 * r;      // D^-1, column of the M-like pivot row
+  const R w20 = -A.sm1 * r, w21 = A.sm0 * r;      // D^-1, column of the C-like pivot row
+  const R al = A.sc0 * w10 + A.sc1 * w11, be = A.sc0 * w20 + A.sc1 * w21;
+  const R ga = B.pm0 * w10 + B.pm1 * w11, ep = B.pm0 * w20 + B.pm1 * w21;
+  e.w10 = w10; e.w11 = w11; e.w20 = w20; e.w21 = w21;
+  e.pm0 = A.pm0; e.pm1 = A.pm1; e.qm = A.qm; e.sc0 = B.sc0; e.sc1 = B.sc1; e.qc = B.qc;
+  Seg<R> o;
+  o.pc0 = A.pc0 - al * A.pm0; o.pc1 = A.pc1 - al * A.pm1;
+  o.sc0 = -be * B.sc0;        o.sc1 = -be * B.sc1;
+  o.qc = A.qc - al * A.qm - be * B.qc;
+  o.pm0 = -ga * A.pm0;        o.pm1 = -ga * A.pm1;
+  o.sm0 = B.sm0 - ep * B.sc0; o.sm1 = B.sm1 - ep * B.sc1;
+  o.qm = B.qm - ga * A.qm - ep * B.qc;
+  O = o;
+}
+
+template <typename R>
+__device__ __forceinline__ void back(const Elim<R> &e, R dL0, R dL1, R dR0, R dR1, R &d0, R &d1) {
+  const R sig = e.qm - (e.pm0 * dL0 + e.pm1 * dL1);
+  const R tau = e.qc - (e.sc0 * dR0 + e.sc1 * dR1);
+  d0 = e.w10 * sig + e.w20 * tau;
+  d1 = e.w11 * sig + e.w21 * tau;
+}
+
+// closes segment S (first node .. last node of the reach) with the two boundary rows
+template <typename R>
+__device__ __forceinline__ void close_system(const Seg<R> &S, const BCRow<R> &U, const BCRow<R> &Dn,
+                                             R &a0, R &a1, R &z0, R &z1) {
+  // block row 0 = {U, C-like}: d_first = g - x * (sc . d_last)
+  const R r0 = frcp(U.dh * S.pc1 - U.dq * S.pc0);
+  const R ru = -U.res, rd = -Dn.res;
+  const R g0 = (S.pc1 * ru - U.dq * S.qc) * r0, g1 = (-S.pc0 * ru + U.dh * S.qc) * r0;
+  const R x0 = -U.dq * r0, x1 = U.dh * r0;
+  const R k = S.pm0 * x0 + S.pm1 * x1;
+  const R m0 = S.sm0 - k * S.sc0, m1 = S.sm1 - k * S.sc1;
+  const R rm = S.qm - (S.pm0 * g0 + S.pm1 * g1);
+  const R r1 = frcp(m0 * Dn.dq - m1 * Dn.dh);
+  z0 = (Dn.dq * rm - m1 * rd) * r1;
+  z1 = (-Dn.dh * rm + m0 * rd) * r1;
+  const R t = S.sc0 * z0 + S.sc1 * z1;
+  a0 = g0 - x0 * t;
+  a1 = g1 - x1 * t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cross-lane plumbing (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ R shfl_up_(R v, int d) { return __shfl_up(v, d, 64); }
+template <typename R> __device__ __forceinline__ R shfl_dn_(R v, int d) { return __shfl_down(v, d, 64); }
+template <typename R> __device__ __forceinline__ R shfl_(R v, int l) { return __shfl(v, l, 64); }
+
+template <typename R> __device__ __forceinline__ Seg<R> seg_shfl_up(const Seg<R> &s, int d) {
+  Seg<R> o;
+  o.pc0 = shfl_up_(s.pc0, d); o.pc1 = shfl_up_(s.pc1, d); o.sc0 = shfl_up_(s.sc0, d); o.sc1 = shfl_up_(s.sc1, d);
+  o.qc = shfl_up_(s.qc, d); o.pm0 = shfl_up_(s.pm0, d); o.pm1 = shfl_up_(s.pm1, d); o.sm0 = shfl_up_(s.sm0, d);
+  o.sm1 = shfl_up_(s.sm1, d); o.qm = shfl_up_(s.qm, d);
+  return o;
+}
+template <typename R> __device__ __forceinline__ R wave_sum(R v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace fs

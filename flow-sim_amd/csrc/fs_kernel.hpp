@@ -1,0 +1,426 @@
+// fs_kernel.hpp - the fused Preissmann time-step kernel for gfx950 (MI355X).
+//
+// One workgroup of W wavefronts advances ONE reach through n_steps time levels; the whole Newton
+// loop of a level (residual, Jacobian, linear solve, norm, update - reference
+// src/hydromodel/preissmann.py:101-163) runs on chip:
+//
+//   * lane t owns the M consecutive cells [t*M, (t+1)*M) and keeps their unknowns (h, Q) in
+//     registers for the whole launch (M+1 nodes, the last one shared with lane t+1);
+//   * the level-(k) halves of the 4-point Preissmann stencil (preissmann.py:899-910) are reduced
+//     to 4 constants per cell, kept in LDS, written once per level, read once per iteration;
+//   * the 2x2-block banded Jacobian is never materialised: each cell's 8 entries
+//     (preissmann.py:407-733) are folded straight into the lane's running segment
+//     (fs_device.hpp), the 64*W lane segments are reduced by a log-depth tree with wavefront
+//     shuffles (levels inside a wave) and LDS (across waves), the two boundary rows close the
+//     system, separators come back down the tree and each lane back-substitutes its chunk;
+//   * HBM is touched once per level per node: the accepted iterate is written as level k
+//     (preissmann.py:166-177; SURVEY F2: it is the pre-update iterate) and read back only by the
+//     next launch.  Boundary hydrographs and iteration counts go to small per-level tables.
+//
+// Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach.
+#pragma once
+#include "fs_device.hpp"
+
+namespace fs {
+
+template <typename R> struct KernelArgs {
+  int32_t B, N, n_steps, level0, max_iter;
+  R theta, dt, dx, tol;
+  R *hk, *Qk;              // [B][N] accepted state of the current level (in: level0, out: level0+n_steps)
+  R *hg, *Qg;              // [B][N] Newton start vector for the next level
+  const R *geo_uniform;    // RECT_UNIFORM: [FS_RU_NPARAM][B]
+  const R *geo_table;      // TABLE: [FS_GEO_NPARAM][N]
+  const R *n_override;     // TABLE: [B] or nullptr
+  BCDesc<R> us, ds;
+  R *Yprev;                // [B] storage stage of the current level
+  R *hydro;                // [levels][4][B]
+  int32_t *iters;          // [levels][B]
+  int32_t *status;         // [B]
+  R *hist_h, *hist_Q;      // [levels][B][N] or nullptr
+};
+
+template <typename R, int SEC> struct Geometry;
+
+template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
+  static constexpr bool kConstT = true;      // dA/dh = b everywhere: no per-node top width to keep
+  R b, rb, n, z_us, z_ds, inv_nm1, dz;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+    b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
+    n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
+    z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach];
+    z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
+    rb = R(1) / b;
+    inv_nm1 = R(1) / R(a.N - 1);
+    dz = (z_ds - z_us) * inv_nm1;
+  }
+  __device__ __forceinline__ R bed_step(int) const { return dz; }   // bed(node+1) - bed(node)
+  __device__ __forceinline__ R terms_T() const { return b; }
+  // distance-weighted interpolation between the two end sections (cross_section.py:887-900)
+  __device__ __forceinline__ R bed(int node) const {
+    const R w2 = R(node) * inv_nm1;
+    return z_us * (R(1) - w2) + z_ds * w2;
+  }
+  __device__ __forceinline__ NodeTerms<R> terms(int, R h, R Q) const { return node_terms_rect(b, rb, n, h, Q); }
+  __device__ __forceinline__ SecParams<R> section(int node) const {
+    SecParams<R> s;
+    s.z = bed(node); s.b = b; s.m = R(0); s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
+    s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
+    return s;
+  }
+};
+
+template <typename R> struct Geometry<R, FS_SEC_TABLE> {
+  static constexpr bool kConstT = false;
+  const R *tab;
+  int N;
+  R n_over;
+  bool has_over;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+    tab = a.geo_table; N = a.N;
+    has_over = a.n_override != nullptr;
+    n_over = has_over ? a.n_override[reach] : R(0);
+  }
+  __device__ __forceinline__ R terms_T() const { return R(0); }      // unused (kConstT == false)
+  __device__ __forceinline__ R bed_step(int node) const {
+    return tab[(size_t)FS_GEO_Z_BED * N + min(node + 1, N - 1)] - tab[(size_t)FS_GEO_Z_BED * N + min(node, N - 1)];
+  }
+  __device__ __forceinline__ R bed(int node) const { return tab[(size_t)FS_GEO_Z_BED * N + node]; }
+  __device__ __forceinline__ SecParams<R> section(int node) const {
+    SecParams<R> s;
+    auto g = [&](int row) { return tab[(size_t)row * N + node]; };
+    s.z = g(FS_GEO_Z_BED); s.b = g(FS_GEO_B_MAIN); s.m = g(FS_GEO_M_MAIN);
+    s.nm = has_over ? n_over : g(FS_GEO_N_MAIN);
+    s.nl = g(FS_GEO_N_LEFT); s.nr = g(FS_GEO_N_RIGHT);
+    s.compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
+    s.hbf = g(FS_GEO_H_BANKFULL); s.bl = g(FS_GEO_B_FP_LEFT); s.br = g(FS_GEO_B_FP_RIGHT);
+    s.mfp = g(FS_GEO_M_FP); s.curv = g(FS_GEO_CURVATURE);
+    return s;
+  }
+  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
+    return node_terms_general(section(node), h, Q);
+  }
+};
+
+// LDS carve-up for one reach
+template <typename R, int M, int W> struct Smem {
+  static constexpr int T = 64 * W;
+  R kc[4][M][T];           // per-cell level-k constants, lane-minor (conflict-free ds_read_b64)
+  R tree[W][10][64];       // per-wave spill slots of the in-wave tree (63 used)
+  R xseg[2][W][10];        // wave segments, double-buffered by iteration parity
+  R xbc[2][8];             // boundary rows: U(dh,dq,res) D(dh,dq,res)
+  R xnorm[2][W];
+  int32_t xflag[2];
+};
+
+// What back-substitution needs for an interior node j of a lane's chunk: the M-like row of the
+// running segment [first node .. j] (sm, pm, qm), 1/det of the pivot block and the continuity
+// right-hand side of cell j.  The continuity coefficients themselves (T_j/(2dt), -+theta/dx) are
+// recomputed.
+template <typename R> struct LocalElim { R r, sm0, sm1, pm0, pm1, qm, qc; };
+
+template <typename R, int SEC, int M, int W>
+__global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArgs<R> a) {
+  constexpr int T = 64 * W;
+  using Geo = Geometry<R, SEC>;
+  __shared__ Smem<R, M, W> sm;
+
+  const int reach = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int N = a.N, NC = N - 1;
+  const int s0 = t * M;                       // first node / cell of this lane
+  const int tD = (NC - 1) / M;                // lane that owns the last real cell
+  const int jD = NC - tD * M;                 // local index (1..M) of node N-1 in that lane
+  const size_t base = (size_t)reach * N;
+
+  Geo geo;
+  geo.init(a, reach);
+
+  const R th = a.theta, dt = a.dt;
+  const R r2dt = R(1) / (R(2) * dt);
+  const R cq = th / a.dx;                     // theta/dx
+  const R cqk = (R(1) - th) / a.dx;           // (1-theta)/dx
+  const R hth = R(0.5) * th, hthk = R(0.5) * (R(1) - th);
+  const R g = R(kG);
+
+  // ---- unknowns of this lane: nodes s0 .. s0+M (clamped copies beyond the last node) ----
+  R h[M + 1], Q[M + 1];
+  R QoldD = R(0);                              // flow[k] at the last node (vol_in of the storage BC)
+
+  // level-k constants of the 4-point stencil from the accepted state (h, Q) of level k:
+  //   C = [sumA]/(2dt) + cq*dQ                 + kc0
+  //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + g*(hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)
+  auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+    NodeTerms<R> L = geo.terms(min(s0, N - 1), hh[0], QQ[0]);
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
+      const R sumA = L.A + Rn.A;
+      sm.kc[0][c][t] = -sumA * r2dt + cqk * (QQ[c + 1] - QQ[c]);
+      sm.kc[1][c][t] = -(QQ[c + 1] + QQ[c]) * r2dt + cqk * (QQ[c + 1] * Rn.v - QQ[c] * L.v);
+      sm.kc[2][c][t] = hthk * sumA;
+      sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (L.Se + Rn.Se);
+      L = Rn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+#pragma unroll
+  for (int j = 0; j <= M; ++j) {
+    const int node = min(s0 + j, N - 1);
+    h[j] = a.hg[base + node];  Q[j] = a.Qg[base + node];
+  }
+  // per-lane base pointers: every later access is base + immediate offset
+  R *const hk_p = a.hk + base + s0, *const Qk_p = a.Qk + base + s0;
+  R *const hg_p = a.hg + base + s0, *const Qg_p = a.Qg + base + s0;
+
+  R Yprev = (a.ds.kind == FS_BC_STORAGE && t == tD) ? a.Yprev[reach] : R(0);
+  int status = a.status[reach];
+  int parity = 0;
+  if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
+  __syncthreads();
+
+  for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
+    const int level = a.level0 + step + 1;
+    {   // accepted state of level k -> 4 constants per cell in LDS (own stores of the previous level are visible)
+      R hk[M + 1], Qk[M + 1];
+#pragma unroll
+      for (int j = 0; j <= M; ++j) {
+        const int node = min(s0 + j, N - 1);
+        hk[j] = a.hk[base + node]; Qk[j] = a.Qk[base + node];
+      }
+      if (t == tD) {
+#pragma unroll
+        for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Qk[j];
+      }
+      write_level_constants(hk, Qk);
+    }
+    int it = 0;
+    bool converged = false;
+    R Ynew = Yprev;
+    while (!converged && status == FS_OK) {
+      ++it;
+      if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
+      parity ^= 1;
+
+      // ================= 1. local assembly + fold (registers only) =================
+      const R *kcb = &sm.kc[0][0][t];
+      asm volatile("" : "+v"(kcb));        // opaque: no hoisting of the 4*M loads out of the Newton loop
+      LocalElim<R> el[M > 1 ? M - 1 : 1];
+      R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
+      Seg<R> seg;
+      R nrm2 = R(0);
+      {
+        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+        if (!Geo::kConstT) Tn[0] = L.T;
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+          const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+          if (!Geo::kConstT) Tn[c + 1] = Rn.T;
+          Seg<R> cell;
+          {
+            const bool real = s0 + c < NC;       // else identity padding: d_{i+1} = d_i
+            const R sumA = L.A + Rn.A;
+            const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + kcb[(0 * M + c) * T];          // :220-249
+            const R avgA = hth * sumA + kcb[(2 * M + c) * T];
+            const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + kcb[(3 * M + c) * T];
+            const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + kcb[(1 * M + c) * T] +
+                           g * avgA * S;                                                     // :251-301
+            nrm2 += real ? Cres * Cres + Mres * Mres : R(0);
+            const R gA = g * avgA, gS = g * hth * S;
+            cell.pc0 = real ? L.T * r2dt : R(1);   cell.pc1 = real ? -cq : R(0);             // :431-447, :476-491
+            cell.sc0 = real ? Rn.T * r2dt : R(-1); cell.sc1 = real ? cq : R(0);              // :407-422, :456-471
+            cell.qc = real ? -Cres : R(0);
+            cell.pm0 = real ? cq * L.v * L.v * L.T + gA * (hth * L.eA - cq) + gS * L.T : R(0);        // :558-612
+            cell.pm1 = real ? r2dt - cq * R(2) * L.v + gA * hth * L.eQ : R(1);                         // :677-733
+            cell.sm0 = real ? -cq * Rn.v * Rn.v * Rn.T + gA * (hth * Rn.eA + cq) + gS * Rn.T : R(0);  // :496-550
+            cell.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
+            cell.qm = real ? -Mres : R(0);
+          }
+          if (c == 0) {
+            seg = cell;
+          } else {
+            // merge(seg, cell) keeping only what the local back-substitution reads
+            const R det = seg.sm0 * cell.pc1 - seg.sm1 * cell.pc0;
+            const R r = frcp(det);
+            LocalElim<R> &e = el[c - 1];
+            e.r = r; e.sm0 = seg.sm0; e.sm1 = seg.sm1; e.pm0 = seg.pm0; e.pm1 = seg.pm1; e.qm = seg.qm; e.qc = cell.qc;
+            const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
+            const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
+            const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
+            Seg<R> o;
+            o.pc0 = seg.pc0 - al * seg.pm0; o.pc1 = seg.pc1 - al * seg.pm1;
+            o.sc0 = -be * cell.sc0;         o.sc1 = -be * cell.sc1;
+            o.qc = seg.qc - al * seg.qm - be * cell.qc;
+            o.pm0 = -ga * seg.pm0;          o.pm1 = -ga * seg.pm1;
+            o.sm0 = cell.sm0 - ep * cell.sc0; o.sm1 = cell.sm1 - ep * cell.sc1;
+            o.qm = cell.qm - ga * seg.qm - ep * cell.qc;
+            seg = o;
+          }
+          L = Rn;
+          __builtin_amdgcn_sched_barrier(0);   // keep the schedule cell by cell: bounded live ranges
+        }
+      }
+
+      // ================= 2. boundary rows =================
+      if (t == 0) {
+        R dummy; int flag = 0;
+        const BCRow<R> U = bc_eval(a.us, reach, a.B, level, geo.section(0), h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
+        nrm2 += U.res * U.res;
+      }
+      if (t == tD) {
+        R hD = h[0], QD = Q[0];
+        int flag = 0;
+#pragma unroll
+        for (int j = 1; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+        const BCRow<R> Dn = bc_eval(a.ds, reach, a.B, level, geo.section(N - 1), hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
+        nrm2 += Dn.res * Dn.res;
+        if (flag) sm.xflag[parity] = flag;
+      }
+
+      // ================= 3. in-wave tree (up-sweep) =================
+#pragma unroll
+      for (int l = 0; l < 6; ++l) {
+        const int d = 1 << l;
+        const Seg<R> left = seg_shfl_up(seg, d);
+        Seg<R> mg; Elim<R> e;
+        merge(left, seg, mg, e);
+        if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+          const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
+          R *p = &sm.tree[wave][0][slot];
+          p[0 * 64] = e.w10; p[1 * 64] = e.w11; p[2 * 64] = e.w20; p[3 * 64] = e.w21; p[4 * 64] = e.pm0;
+          p[5 * 64] = e.pm1; p[6 * 64] = e.qm;  p[7 * 64] = e.sc0; p[8 * 64] = e.sc1; p[9 * 64] = e.qc;
+          seg = mg;
+        }
+      }
+      nrm2 = wave_sum(nrm2);
+      if (lane == 63) {
+        R *p = sm.xseg[parity][wave];
+        p[0] = seg.pc0; p[1] = seg.pc1; p[2] = seg.sc0; p[3] = seg.sc1; p[4] = seg.qc;
+        p[5] = seg.pm0; p[6] = seg.pm1; p[7] = seg.sm0; p[8] = seg.sm1; p[9] = seg.qm;
+        sm.xnorm[parity][wave] = nrm2;
+      }
+      __syncthreads();
+
+      // ================= 4. across waves: fold, close with the boundary rows, unfold =================
+      R tot = R(0);
+      R bL0, bL1, bR0, bR1;          // updates at the first / last node of this wave's span
+      {
+        Seg<R> acc;
+        Elim<R> we[W > 1 ? W - 1 : 1];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const R *p = sm.xseg[parity][w];
+          Seg<R> sw;
+          sw.pc0 = p[0]; sw.pc1 = p[1]; sw.sc0 = p[2]; sw.sc1 = p[3]; sw.qc = p[4];
+          sw.pm0 = p[5]; sw.pm1 = p[6]; sw.sm0 = p[7]; sw.sm1 = p[8]; sw.qm = p[9];
+          tot += sm.xnorm[parity][w];
+          if (w == 0) acc = sw;
+          else merge(acc, sw, acc, we[w - 1]);
+        }
+        BCRow<R> U, Dn;
+        U.dh = sm.xbc[parity][0]; U.dq = sm.xbc[parity][1]; U.res = sm.xbc[parity][2];
+        Dn.dh = sm.xbc[parity][3]; Dn.dq = sm.xbc[parity][4]; Dn.res = sm.xbc[parity][5];
+        R bnd[W + 1][2];
+        close_system(acc, U, Dn, bnd[0][0], bnd[0][1], bnd[W][0], bnd[W][1]);
+#pragma unroll
+        for (int w = W - 1; w >= 1; --w)
+          back(we[w - 1], bnd[0][0], bnd[0][1], bnd[w + 1][0], bnd[w + 1][1], bnd[w][0], bnd[w][1]);
+        bL0 = bnd[0][0]; bL1 = bnd[0][1]; bR0 = bnd[1][0]; bR1 = bnd[1][1];
+#pragma unroll
+        for (int w = 1; w < W; ++w)
+          if (wave == w) { bL0 = bnd[w][0]; bL1 = bnd[w][1]; bR0 = bnd[w + 1][0]; bR1 = bnd[w + 1][1]; }
+      }
+      const R err = sqrt_(tot);                                        // utility.py:20-22
+      if (sm.xflag[parity] != 0) status = sm.xflag[parity];
+      if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
+      converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
+
+      // ================= 5. accepted iterate -> level k =================
+      if (converged) {
+        if (t == 0) {
+          a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
+          a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
+          a.iters[(size_t)level * a.B + reach] = it;
+        }
+        {
+          R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+#pragma unroll
+          for (int j = 0; j <= M; ++j) {
+            const int node = s0 + j;
+            if ((j < M || node == N - 1) && node < N) {
+              hk_p[j] = h[j]; Qk_p[j] = Q[j];
+              if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
+            }
+          }
+        }
+        if (t == tD) {
+#pragma unroll
+          for (int j = 1; j <= M; ++j)
+            if (j == jD) {
+              a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
+              a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
+            }
+          Yprev = Ynew;
+        }
+      }
+
+      // ================= 6. separators down the tree, local back-substitution, update ============
+      R dR0 = bR0, dR1 = bR1;       // valid on lane 63; filled for every lane below
+#pragma unroll
+      for (int l = 5; l >= 0; --l) {
+        const int d = 1 << l;
+        R e0 = shfl_up_(dR0, 2 * d), e1 = shfl_up_(dR1, 2 * d);
+        if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
+        R m0 = R(0), m1 = R(0);
+        if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+          const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
+          const R *p = &sm.tree[wave][0][slot];
+          Elim<R> e;
+          e.w10 = p[0 * 64]; e.w11 = p[1 * 64]; e.w20 = p[2 * 64]; e.w21 = p[3 * 64]; e.pm0 = p[4 * 64];
+          e.pm1 = p[5 * 64]; e.qm = p[6 * 64];  e.sc0 = p[7 * 64]; e.sc1 = p[8 * 64]; e.qc = p[9 * 64];
+          back(e, e0, e1, dR0, dR1, m0, m1);
+        }
+        const R x0 = shfl_dn_(m0, d), x1 = shfl_dn_(m1, d);
+        if ((lane & (2 * d - 1)) == (d - 1)) { dR0 = x0; dR1 = x1; }
+      }
+      R dL0 = shfl_up_(dR0, 1), dL1 = shfl_up_(dR1, 1);
+      if (lane == 0) { dL0 = bL0; dL1 = bL1; }
+
+      R n0 = dR0, n1 = dR1;
+      h[M] += dR0; Q[M] += dR1;
+#pragma unroll
+      for (int j = M - 1; j >= 1; --j) {
+        const LocalElim<R> &e = el[j - 1];
+        // pivot block rows: (sm0, sm1) and the continuity row of cell j: (T_j/(2dt), -cq | T_{j+1}/(2dt), cq)
+        const R pc0 = (Geo::kConstT ? geo.terms_T() : Tn[j]) * r2dt;
+        const R sc0 = (Geo::kConstT ? geo.terms_T() : Tn[j + 1]) * r2dt;
+        const bool real = s0 + j < NC;      // cell j is a real cell (else identity padding)
+        const R c0 = real ? pc0 : R(1), c1 = real ? -cq : R(0);
+        const R b0 = real ? sc0 : R(-1), b1 = real ? cq : R(0);
+        const R sig = e.qm - (e.pm0 * dL0 + e.pm1 * dL1);
+        const R tau = e.qc - (b0 * n0 + b1 * n1);
+        const R d0 = e.r * (c1 * sig - e.sm1 * tau);
+        const R d1 = e.r * (e.sm0 * tau - c0 * sig);
+        h[j] += d0; Q[j] += d1;
+        n0 = d0; n1 = d1;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      h[0] += dL0; Q[0] += dL1;                                        // preissmann.py:146-147
+    }
+    if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
+  }
+
+  // ---- Newton start vector of the next level + per-reach bookkeeping ----
+#pragma unroll
+  for (int j = 0; j <= M; ++j) {
+    const int node = s0 + j;
+    if ((j < M || node == N - 1) && node < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
+  }
+  if (t == 0) a.status[reach] = status;
+  if (a.ds.kind == FS_BC_STORAGE && t == tD) a.Yprev[reach] = Yprev;
+}
+
+}  // namespace fs

@@ -1,0 +1,102 @@
+"""ctypes binding of include/flowsim_abi.h.
+
+The HIP library is the product; there is no Python or CPU fallback.  If libflowsim_hip.so has not
+been built (`python -c "import __graft_entry__ as g; g.build()"`) or no MI355X is visible, the
+calls below raise - loudly - instead of computing anything on the host.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "..", "csrc", "libflowsim_hip.so")
+
+F64, F32 = 0, 1
+SEC_RECT_UNIFORM, SEC_TABLE = 0, 2
+RU_WIDTH, RU_MANNING, RU_Z_US, RU_Z_DS, RU_NPARAM = 0, 1, 2, 3, 4
+GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
+            "b_fp_l", "b_fp_r", "m_fp", "curvature")
+GEO_NPARAM = len(GEO_ROWS)
+(BC_FLOW_HYDROGRAPH, BC_STAGE_HYDROGRAPH, BC_FIXED_DEPTH, BC_NORMAL_DEPTH, BC_RATING_POWER,
+ BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE) = range(8)
+UPSTREAM, DOWNSTREAM = 0, 1
+OK, MAX_ITER, NAN, STORAGE_RANGE = 0, 1, 2, 3
+FLAG_HISTORY = 1
+ABI_VERSION = 1
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_reaches", C.c_int32), ("n_nodes", C.c_int32), ("dtype", C.c_int32),
+                ("section_mode", C.c_int32), ("device", C.c_int32), ("max_levels", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); must list every function declared in include/flowsim_abi.h
+SIGNATURES = {
+    "fs_abi_version": (C.c_int, []),
+    "fs_device_count": (C.c_int, []),
+    "fs_last_error": (C.c_char_p, []),
+    "fs_batch_create": (_P, [C.POINTER(BatchDesc)]),
+    "fs_batch_destroy": (None, [_P]),
+    "fs_batch_set_scheme": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32]),
+    "fs_batch_set_geometry_uniform": (C.c_int, [_P, _D]),
+    "fs_batch_set_geometry_table": (C.c_int, [_P, _D, _D]),
+    "fs_batch_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, _D, C.c_int32, C.c_int32, _D]),
+    "fs_batch_set_state": (C.c_int, [_P, _D, _D]),
+    "fs_batch_step": (C.c_int, [_P, C.c_int32]),
+    "fs_batch_sync": (C.c_int, [_P]),
+    "fs_batch_level": (C.c_int32, [_P]),
+    "fs_batch_get_state": (C.c_int, [_P, _D, _D]),
+    "fs_batch_get_guess": (C.c_int, [_P, _D, _D]),
+    "fs_batch_get_hydrographs": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
+    "fs_batch_get_iterations": (C.c_int, [_P, C.c_int32, C.c_int32, _I]),
+    "fs_batch_get_status": (C.c_int, [_P, _I]),
+    "fs_batch_get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D]),
+    "fs_batch_get_storage_stage": (C.c_int, [_P, _D]),
+    "fs_batch_hydrograph_device_ptr": (_P, [_P]),
+    "fs_batch_stream": (_P, [_P]),
+    "fs_batch_last_step_ms": (C.c_double, [_P]),
+    "fs_batch_last_launch_count": (C.c_int32, [_P]),
+    "fs_batch_kernel_info": (C.c_int, [_P, _I, _I, _I, _I]),
+}
+
+_lib = None
+
+
+class FlowsimError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libflowsim_hip.so (once).  Raises FlowsimError if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = os.path.normpath(LIB_PATH)
+        if not os.path.exists(path):
+            raise FlowsimError(
+                f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
+                "g.build()' or make -C flow-sim_amd/csrc).  There is no CPU fallback.")
+        l = C.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.fs_abi_version() != ABI_VERSION:
+            raise FlowsimError(f"ABI mismatch: library {l.fs_abi_version()}, binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def last_error():
+    return lib().fs_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise FlowsimError(f"{what}: {last_error()}" if what else last_error())
+
+
+def device_count():
+    return lib().fs_device_count()

@@ -1,0 +1,186 @@
+"""PreissmannBatch - B independent reaches advanced together on one MI355X through the C ABI.
+
+Host-side mirror of the state the reference's PreissmannSolver carries (preissmann.py:23-59,
+solver.py:11-51): scheme parameters, node geometry, two boundaries, initial conditions; `step(n)`
+is the batched equivalent of n passes of the outer loop of PreissmannSolver.run
+(preissmann.py:108-161).  All arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _abi as A
+
+_KIND_PARAMS = {
+    A.BC_FLOW_HYDROGRAPH: (), A.BC_STAGE_HYDROGRAPH: ("bed_level",), A.BC_FIXED_DEPTH: ("initial_depth",),
+    A.BC_NORMAL_DEPTH: ("bed_slope", "bed_level"), A.BC_RATING_POWER: ("a", "b", "stage_shift", "bed_level"),
+    A.BC_RATING_POLY: ("a", "b", "c", "stage_shift", "bed_level"),
+    A.BC_RATING_BLEND: ("stage0", "buffer", "lo0", "lo1", "lo2", "hi0", "hi1", "hi2", "dY", "bed_level"),
+    A.BC_STORAGE: ("surface_area", "min_stage", "Y_min", "Y_max", "bed_level"),
+}
+
+
+@dataclass
+class BoundarySpec:
+    """One boundary of every reach in the batch (Boundary, boundary.py:10-46, flattened).
+
+    params: dict name -> scalar (shared by all reaches) or array [B] (per reach); the names per
+    kind are in _KIND_PARAMS.  target: hydrograph pre-sampled at level*dt, [n_levels] (shared) or
+    [n_levels, B]."""
+    kind: int
+    params: dict = field(default_factory=dict)
+    target: Optional[np.ndarray] = None
+
+
+def _dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class PreissmannBatch:
+    def __init__(self, n_reaches: int, n_nodes: int, max_levels: int, dtype: str = "f64",
+                 section_mode: str = "rect_uniform", device: int = 0, history: bool = False):
+        self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
+        self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
+        self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "table": A.SEC_TABLE}[section_mode]
+        self._lib = A.lib()
+        desc = A.BatchDesc(self.B, self.N, self.dtype, self.mode, device, self.L,
+                           A.FLAG_HISTORY if history else 0, 0)
+        self._h = self._lib.fs_batch_create(C.byref(desc))
+        if not self._h:
+            raise A.FlowsimError(A.last_error())
+        self.history = history
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fs_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- setup ----------------------------------------------------------------------------
+    def set_scheme(self, theta, dt, dx, tolerance=1e-4, max_iter=100):
+        A.check(self._lib.fs_batch_set_scheme(self._h, float(theta), float(dt), float(dx), float(tolerance),
+                                              int(max_iter)), "set_scheme")
+
+    def set_geometry_uniform(self, width, manning, z_us, z_ds):
+        p = np.empty((A.RU_NPARAM, self.B), dtype=np.float64)
+        p[A.RU_WIDTH], p[A.RU_MANNING], p[A.RU_Z_US], p[A.RU_Z_DS] = width, manning, z_us, z_ds
+        A.check(self._lib.fs_batch_set_geometry_uniform(self._h, _dptr(p)), "set_geometry_uniform")
+
+    def set_geometry_table(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):
+        tab = np.empty((A.GEO_NPARAM, self.N), dtype=np.float64)
+        for i, k in enumerate(A.GEO_ROWS):
+            tab[i] = np.asarray(geo[k], dtype=np.float64)
+        ov = None
+        if n_main_override is not None:
+            ov = np.ascontiguousarray(n_main_override, dtype=np.float64)
+            assert ov.shape == (self.B,)
+        A.check(self._lib.fs_batch_set_geometry_table(self._h, _dptr(tab), _dptr(ov) if ov is not None else None),
+                "set_geometry_table")
+
+    def set_boundary(self, side: int, spec: BoundarySpec):
+        names = _KIND_PARAMS[spec.kind]
+        vals = [np.asarray(spec.params[n], dtype=np.float64) for n in names]
+        per_reach = any(v.ndim > 0 for v in vals)
+        if per_reach:
+            p = np.empty((len(names), self.B), dtype=np.float64)
+            for i, v in enumerate(vals):
+                p[i] = v
+        else:
+            p = np.array([float(v) for v in vals], dtype=np.float64)
+        tgt = None
+        if spec.target is not None:
+            t = np.asarray(spec.target, dtype=np.float64)
+            tgt = np.empty((self.L, self.B), dtype=np.float64)
+            n = min(self.L, t.shape[0])
+            tgt[:n] = t[:n, None] if t.ndim == 1 else t[:n]
+            tgt[n:] = tgt[n - 1]
+        A.check(self._lib.fs_batch_set_bc(self._h, side, spec.kind, _dptr(p) if len(names) else None, len(names),
+                                          1 if per_reach else 0, _dptr(tgt) if tgt is not None else None),
+                "set_boundary")
+
+    def set_state(self, h, Q):
+        h = np.ascontiguousarray(np.broadcast_to(np.asarray(h, dtype=np.float64), (self.B, self.N)))
+        Q = np.ascontiguousarray(np.broadcast_to(np.asarray(Q, dtype=np.float64), (self.B, self.N)))
+        A.check(self._lib.fs_batch_set_state(self._h, _dptr(h), _dptr(Q)), "set_state")
+
+    # -- the hot path ---------------------------------------------------------------------
+    def step(self, n_steps: int = 1, sync: bool = True):
+        A.check(self._lib.fs_batch_step(self._h, int(n_steps)), "step")
+        if sync:
+            self.sync()
+
+    def sync(self):
+        A.check(self._lib.fs_batch_sync(self._h), "sync")
+
+    @property
+    def level(self):
+        return self._lib.fs_batch_level(self._h)
+
+    # -- results --------------------------------------------------------------------------
+    def state(self):
+        h = np.empty((self.B, self.N)); Q = np.empty((self.B, self.N))
+        A.check(self._lib.fs_batch_get_state(self._h, _dptr(h), _dptr(Q)), "get_state")
+        return h, Q
+
+    def guess(self):
+        h = np.empty((self.B, self.N)); Q = np.empty((self.B, self.N))
+        A.check(self._lib.fs_batch_get_guess(self._h, _dptr(h), _dptr(Q)), "get_guess")
+        return h, Q
+
+    def hydrographs(self, first=0, n=None):
+        """[n, 4, B]: depth[k,0], flow[k,0], depth[k,-1], flow[k,-1]."""
+        n = self.level + 1 - first if n is None else n
+        out = np.empty((n, 4, self.B))
+        A.check(self._lib.fs_batch_get_hydrographs(self._h, first, n, _dptr(out)), "get_hydrographs")
+        return out
+
+    def iterations(self, first=0, n=None):
+        n = self.level + 1 - first if n is None else n
+        out = np.empty((n, self.B), dtype=np.int32)
+        A.check(self._lib.fs_batch_get_iterations(self._h, first, n, out.ctypes.data_as(C.POINTER(C.c_int32))),
+                "get_iterations")
+        return out
+
+    def status(self):
+        out = np.empty(self.B, dtype=np.int32)
+        A.check(self._lib.fs_batch_get_status(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))), "get_status")
+        return out
+
+    def history_arrays(self, first=0, n=None):
+        """depth, flow [n, B, N] (needs history=True)."""
+        n = self.level + 1 - first if n is None else n
+        h = np.empty((n, self.B, self.N)); Q = np.empty((n, self.B, self.N))
+        A.check(self._lib.fs_batch_get_history(self._h, first, n, _dptr(h), _dptr(Q)), "get_history")
+        return h, Q
+
+    def storage_stage(self):
+        out = np.empty(self.B)
+        A.check(self._lib.fs_batch_get_storage_stage(self._h, _dptr(out)), "get_storage_stage")
+        return out
+
+    def last_step_ms(self):
+        return self._lib.fs_batch_last_step_ms(self._h)
+
+    def kernel_info(self):
+        v = [C.c_int32() for _ in range(4)]
+        A.check(self._lib.fs_batch_kernel_info(self._h, *[C.byref(x) for x in v]), "kernel_info")
+        return dict(cells_per_thread=v[0].value, waves_per_reach=v[1].value, lds_bytes=v[2].value, vgprs=v[3].value)
+
+    def hydrograph_device_ptr(self):
+        return self._lib.fs_batch_hydrograph_device_ptr(self._h)

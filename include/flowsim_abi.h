@@ -1,0 +1,155 @@
+/*
+ * flowsim_abi.h - C ABI of the MI355X-native batched Preissmann stepper (libflowsim_hip.so).
+ *
+ * Drop-in boundary for ONE path of cve-mohd/flow-sim: the per-timestep Newton loop of
+ * PreissmannSolver.run (reference: src/hydromodel/preissmann.py:101-163) together with everything
+ * it calls per node (preissmann.py:61-99, :200-344, :407-798, :899-910; solver.py:244-296;
+ * channel.py:53-105,:172-190; cross_section.py:114-175,:623-793; hydraulics.py:4-229;
+ * boundary.py:56-247; rating_curve.py:32-63,:132-147; lumped_storage.py:24-45) and the sparse
+ * solve it hands to scipy.sparse.linalg.spsolve (preissmann.py:146).
+ *
+ * The reference is pure Python and has no FFI of its own; the binding a maintainer would add is a
+ * ctypes stub inside PreissmannSolver.run (shown in INTEGRATION.md).  Every entry point below
+ * states which reference interface it stands in for.
+ *
+ * Conventions
+ *   - plain C, no torch / numpy types; all host arrays are caller-owned, contiguous, float64
+ *     (also for FS_F32 batches - converted on upload) unless stated otherwise;
+ *   - B = reaches in the batch (independent channels / ensemble members), N = nodes per reach,
+ *     level k = time level (k = 0 is the initial condition);
+ *   - return 0 on success, <0 on error (text via fs_last_error(), thread-local);
+ *   - a handle owns its device buffers and one HIP stream; it is not thread-safe;
+ *   - calls are asynchronous on the handle's stream unless they copy to host memory.
+ */
+#ifndef FLOWSIM_ABI_H
+#define FLOWSIM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+
+typedef struct fs_batch fs_batch;
+
+/* arithmetic type of the path (reference: float64 everywhere, solver.py:43-44) */
+enum { FS_F64 = 0, FS_F32 = 1 };
+
+/* How node geometry reaches the kernel.
+ *   RECT_UNIFORM : one rectangular prismatic channel per reach from per-reach scalars
+ *                  (what Channel(width=, roughness=) builds, channel.py:282-294);
+ *   TABLE        : one [FS_GEO_NPARAM][N] table of TrapezoidalSection parameters at the nodes
+ *                  (cross_section.py:569-613 after interpolation, channel.py:213-241), shared by
+ *                  all reaches, optional per-reach main-channel Manning n
+ *                  (cases/gerd_roseires/custom_functions.py:147). */
+enum { FS_SEC_RECT_UNIFORM = 0, FS_SEC_TABLE = 2 };
+
+/* rows of the RECT_UNIFORM parameter block, each [B] */
+enum { FS_RU_WIDTH = 0, FS_RU_MANNING = 1, FS_RU_Z_US = 2, FS_RU_Z_DS = 3, FS_RU_NPARAM = 4 };
+
+/* rows of the TABLE geometry block, each [N] (TrapezoidalSection attributes) */
+enum {
+  FS_GEO_Z_BED = 0, FS_GEO_B_MAIN, FS_GEO_M_MAIN, FS_GEO_N_MAIN, FS_GEO_N_LEFT, FS_GEO_N_RIGHT,
+  FS_GEO_IS_COMPOUND, FS_GEO_H_BANKFULL, FS_GEO_B_FP_LEFT, FS_GEO_B_FP_RIGHT, FS_GEO_M_FP,
+  FS_GEO_CURVATURE, FS_GEO_NPARAM
+};
+
+/* Boundary.condition (boundary.py:32) flattened; rating_curve split by RatingCurve.type
+ * (rating_curve.py:10-31) plus the smooth Roseires gate curve of cases/gerd_roseires
+ * (roseires_rating_curve.py:65-109,:202-208) and fixed_depth behind a constant-area
+ * LumpedStorage (boundary.py:97-133, lumped_storage.py:24-45). */
+enum {
+  FS_BC_FLOW_HYDROGRAPH = 0,  /* params: -                      ; needs target table          */
+  FS_BC_STAGE_HYDROGRAPH = 1, /* params: bed_level              ; needs target table          */
+  FS_BC_FIXED_DEPTH = 2,      /* params: initial_depth                                        */
+  FS_BC_NORMAL_DEPTH = 3,     /* params: bed_slope, bed_level                                 */
+  FS_BC_RATING_POWER = 4,     /* params: a, b, stage_shift, bed_level                         */
+  FS_BC_RATING_POLY = 5,      /* params: a, b, c, stage_shift, bed_level                      */
+  FS_BC_RATING_BLEND = 6,     /* params: stage0, buffer, lo0, lo1, lo2, hi0, hi1, hi2, dY, bed_level
+                                 Q = (1-s)*lo(z) + s*hi(z), lo/hi quadratics in z, s = smoothstep */
+  FS_BC_STORAGE = 7           /* params: surface_area, min_stage, Y_min, Y_max, bed_level (downstream only) */
+};
+#define FS_BC_MAX_PARAMS 10
+enum { FS_UPSTREAM = 0, FS_DOWNSTREAM = 1 };
+
+/* per-reach status after stepping (preissmann.py:124-126 raises ValueError; :135-137 NaN check) */
+enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3 };
+
+enum { FS_FLAG_HISTORY = 1 };   /* keep depth/flow[level][B][N] on the device (solver.py:43-44) */
+
+typedef struct fs_batch_desc {
+  int32_t n_reaches;     /* B */
+  int32_t n_nodes;       /* N, 2..4097 */
+  int32_t dtype;         /* FS_F64 | FS_F32 */
+  int32_t section_mode;  /* FS_SEC_* */
+  int32_t device;        /* HIP device ordinal */
+  int32_t max_levels;    /* capacity of per-level tables: time levels 0..max_levels-1 (solver.py:35) */
+  int32_t flags;         /* FS_FLAG_* */
+  int32_t reserved;
+} fs_batch_desc;
+
+int fs_abi_version(void);
+int fs_device_count(void);                 /* 0 when no HIP device is visible */
+const char *fs_last_error(void);
+
+/* Solver.__init__ state arrays + PreissmannSolver.__init__ (solver.py:11-51, preissmann.py:23-46) */
+fs_batch *fs_batch_create(const fs_batch_desc *desc);
+void fs_batch_destroy(fs_batch *b);
+
+/* theta / time_step / spatial_step of the solver and tolerance / max_iter of run()
+ * (preissmann.py:23-46, :101; solver.py:32, :53-55) - shared by the whole batch */
+int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double tolerance, int32_t max_iter);
+
+/* RECT_UNIFORM: params[FS_RU_NPARAM][B] */
+int fs_batch_set_geometry_uniform(fs_batch *b, const double *params);
+/* TABLE: table[FS_GEO_NPARAM][N]; n_main_override[B] or NULL */
+int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *n_main_override);
+
+/* one boundary (Boundary.__init__, boundary.py:10-46).  params[n_params] when per_reach == 0,
+ * params[n_params][B] otherwise.  target[max_levels][B] (value at t = level*dt, i.e.
+ * Hydrograph.get_at pre-sampled, hydrograph.py:15-22) or NULL. */
+int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *params, int32_t n_params,
+                    int32_t per_reach, const double *target);
+
+/* Channel.initial_conditions (channel.py:107-138) -> depth[0], flow[0] and the Newton start
+ * vector (solver.py:61-63, preissmann.py:48-59).  h, Q: [B][N].  Resets the level counter. */
+int fs_batch_set_state(fs_batch *b, const double *h, const double *Q);
+
+/* THE HOT PATH: advances every reach by n_steps time levels (preissmann.py:108-161).  Results
+ * stay on the device: boundary hydrographs, Newton counts, status, (history).  Asynchronous. */
+int fs_batch_step(fs_batch *b, int32_t n_steps);
+int fs_batch_sync(fs_batch *b);
+int32_t fs_batch_level(const fs_batch *b);   /* current time level k */
+
+/* depth[k], flow[k] of the current level (what update_guesses stored, preissmann.py:166-177) */
+int fs_batch_get_state(fs_batch *b, double *h, double *Q);
+/* the post-update Newton vector that seeds the next level (preissmann.py:146-147) */
+int fs_batch_get_guess(fs_batch *b, double *h, double *Q);
+/* out[n_levels][4][B] = depth[k,0], flow[k,0], depth[k,-1], flow[k,-1] for k = first..first+n-1
+ * (what cases read from solver.depth / solver.flow, cases/gerd_roseires/model.py:107-111) */
+int fs_batch_get_hydrographs(fs_batch *b, int32_t first_level, int32_t n_levels, double *out);
+int fs_batch_get_iterations(fs_batch *b, int32_t first_level, int32_t n_levels, int32_t *out); /* [n][B] */
+int fs_batch_get_status(fs_batch *b, int32_t *out);                                            /* [B]   */
+/* FS_FLAG_HISTORY only: h, Q [n_levels][B][N] (solver.depth / solver.flow, solver.py:43-44) */
+int fs_batch_get_history(fs_batch *b, int32_t first_level, int32_t n_levels, double *h, double *Q);
+/* reservoir stage kept per level by the storage boundary (boundary.py:126-131): out[B] */
+int fs_batch_get_storage_stage(fs_batch *b, double *out);
+
+/* zero-copy access for device-side consumers (RCCL gather of hydrographs): device pointer to the
+ * [max_levels][4][B] hydrograph block in the batch dtype, and the handle's hipStream_t */
+void *fs_batch_hydrograph_device_ptr(fs_batch *b);
+void *fs_batch_stream(fs_batch *b);
+
+/* measurement: HIP-event time of the kernels launched by the last fs_batch_step (ms, after
+ * fs_batch_sync), their count, and the launch geometry chosen for this batch */
+double fs_batch_last_step_ms(fs_batch *b);
+int32_t fs_batch_last_launch_count(fs_batch *b);
+int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach,
+                         int32_t *lds_bytes, int32_t *vgprs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOWSIM_ABI_H */

@@ -1,0 +1,71 @@
+"""Builds a PreissmannBatch (the HIP product path, through the C ABI) from a golden fixture."""
+import numpy as np
+
+from flowsim_amd import BoundarySpec, PreissmannBatch
+from flowsim_amd import _abi as A
+from oracle import preissmann_oracle as O
+
+
+def boundary_spec(bc: O.BC, nt):
+    k = bc.kind
+    if k == "flow_hydrograph":
+        return BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, bc.target)
+    if k == "stage_hydrograph":
+        return BoundarySpec(A.BC_STAGE_HYDROGRAPH, dict(bed_level=bc.bed_level), bc.target)
+    if k == "fixed_depth" and bc.storage is None:
+        return BoundarySpec(A.BC_FIXED_DEPTH, dict(initial_depth=bc.initial_depth))
+    if k == "fixed_depth":
+        s = bc.storage
+        return BoundarySpec(A.BC_STORAGE, dict(surface_area=s["area"], min_stage=s["min_stage"], Y_min=s["Y_min"],
+                                               Y_max=s["Y_max"], bed_level=bc.bed_level))
+    if k == "normal_depth":
+        return BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=bc.bed_slope, bed_level=bc.bed_level))
+    if k == "rating_curve":
+        rc = bc.rc
+        if bc.rc_type == "power":
+            return BoundarySpec(A.BC_RATING_POWER, dict(a=rc["a"], b=rc["b"], stage_shift=rc.get("shift", 0.0),
+                                                        bed_level=bc.bed_level))
+        if bc.rc_type == "polynomial":
+            return BoundarySpec(A.BC_RATING_POLY, dict(a=rc["a"], b=rc["b"], c=rc["c"],
+                                                       stage_shift=rc.get("shift", 0.0), bed_level=bc.bed_level))
+        return BoundarySpec(A.BC_RATING_BLEND, dict(stage0=rc["initial_stage"], buffer=rc["buffer"],
+                                                    lo0=rc["low"][0], lo1=rc["low"][1], lo2=rc["low"][2],
+                                                    hi0=rc["high"][0], hi1=rc["high"][1], hi2=rc["high"][2],
+                                                    dY=rc.get("dY", 1e-3), bed_level=bc.bed_level))
+    raise ValueError(k)
+
+
+def merge_specs(specs, B):
+    """Per-reach parameter arrays from a list of B single-reach specs of the same kind."""
+    kind = specs[0].kind
+    assert all(s.kind == kind for s in specs)
+    params = {k: np.array([s.params[k] for s in specs], dtype=np.float64) for k in specs[0].params}
+    tgt = None
+    if specs[0].target is not None:
+        tgt = np.stack([np.asarray(s.target, dtype=np.float64) for s in specs], axis=1)
+    return BoundarySpec(kind, params, tgt)
+
+
+def is_rect_uniform(p: O.Problem):
+    g = p.geo
+    return (np.all(g["is_compound"] < 0.5) and np.all(g["m_main"] == 0) and np.all(g["curvature"] == 0)
+            and np.ptp(g["b_main"]) == 0 and np.ptp(g["n_main"]) == 0)
+
+
+def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main_override=None):
+    """One batch from a list of oracle Problems that share N, nt and the scheme parameters."""
+    p0 = problems[0]
+    B = len(problems)
+    if mode == "auto":
+        mode = "rect_uniform" if all(is_rect_uniform(p) for p in problems) else "table"
+    b = PreissmannBatch(B, p0.N, p0.nt, dtype=dtype, section_mode=mode, history=history)
+    b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
+    if mode == "rect_uniform":
+        b.set_geometry_uniform([p.geo["b_main"][0] for p in problems], [p.geo["n_main"][0] for p in problems],
+                               [p.geo["z_bed"][0] for p in problems], [p.geo["z_bed"][-1] for p in problems])
+    else:
+        b.set_geometry_table(p0.geo, n_main_override)
+    b.set_boundary(A.UPSTREAM, merge_specs([boundary_spec(p.us, p.nt) for p in problems], B))
+    b.set_boundary(A.DOWNSTREAM, merge_specs([boundary_spec(p.ds, p.nt) for p in problems], B))
+    b.set_state(np.stack([p.h0 for p in problems]), np.stack([p.Q0 for p in problems]))
+    return b

@@ -1,0 +1,179 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors produced by the
+reference and against the CPU oracle on the same inputs.
+
+Tolerance (BASELINE.json north_star / SURVEY 8c): relative stage / discharge error
+max |dh|/max(|h|,1e-3), |dQ|/max(|Q|,1) <= 1e-8 in fp64, identical Newton iteration counts.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import preissmann_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-8
+FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def rel_err(got, want, floor):
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor)))
+
+
+def problems_of(path):
+    fx, meta = O.load_fixture(path)
+    mem = list(range(meta["B"])) if meta.get("B") else [None]
+    return fx, meta, [O.problem_from_fixture(fx, meta, m) for m in mem]
+
+
+def golden(fx, name, i, B, base_ndim):
+    a = fx[name]
+    return a[i] if B and a.ndim > base_ndim else a
+
+
+def run_and_compare(path, mode, shape=None, monkeypatch=None):
+    from fixture_batch import batch_from_problems
+    fx, meta, probs = problems_of(path)
+    B = meta.get("B")
+    if shape:
+        monkeypatch.setenv("FS_KERNEL_SHAPE", shape)
+    override = None
+    if os.path.basename(path).startswith("gerd_ensemble"):
+        override = [float(p.geo["n_main"][0]) for p in probs]      # all sections share one n_main per member
+        for p in probs:
+            assert np.ptp(p.geo["n_main"]) < 1e-15
+    # the TABLE geometry is shared by the whole batch: members with their own channel run one by one
+    shared = override is not None or mode != "table" or all(
+        all(np.array_equal(p.geo[k], probs[0].geo[k]) for k in O.GEO_KEYS) for p in probs)
+    groups = [list(range(len(probs)))] if shared else [[i] for i in range(len(probs))]
+    info = None
+    for grp in groups:
+        with batch_from_problems([probs[i] for i in grp], mode=mode, n_main_override=override) as b:
+            b.step(probs[0].nt - 1)
+            assert np.all(b.status() == 0), b.status()
+            h, Q = b.history_arrays()
+            its = b.iterations()
+            hyd = b.hydrographs()
+            for j, i in enumerate(grp):
+                d, f, it = golden(fx, "depth", i, B, 2), golden(fx, "flow", i, B, 2), golden(fx, "iters", i, B, 1)
+                assert rel_err(h[:, j], d, 1e-3) <= TOL, (path, i)
+                assert rel_err(Q[:, j], f, 1.0) <= TOL, (path, i)
+                assert np.array_equal(its[:, j], it), (path, i, its[:, j], it)
+                assert np.array_equal(hyd[:, 0, j], h[:, j, 0]) and np.array_equal(hyd[:, 3, j], Q[:, j, -1])
+            info = b.kernel_info()
+    return info
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_golden_hydrographs_table_mode(path):
+    run_and_compare(path, "table")
+
+
+@pytest.mark.parametrize("name", ["akbari", "example", "synthetic_rect_64", "synthetic_rect_512", "bc_stage_fixed"])
+def test_golden_hydrographs_rect_fast_path(name):
+    run_and_compare(os.path.join(GOLDEN, name + ".npz"), "rect_uniform")
+
+
+@pytest.mark.parametrize("shape", ["1,1", "2,1", "4,1", "8,1", "16,1", "16,2", "16,4"])
+def test_every_kernel_shape_on_small_reach(shape, monkeypatch):
+    """Same answers whatever the cells-per-lane / waves-per-reach split (padding, cross-wave fold)."""
+    m, w = map(int, shape.split(","))
+    for name in ("synthetic_rect_64", "akbari"):
+        path = os.path.join(GOLDEN, name + ".npz")
+        fx, meta = O.load_fixture(path)
+        if 64 * m * w < meta["N"] - 1:
+            continue
+        info = run_and_compare(path, "rect_uniform", shape, monkeypatch)
+        assert (info["cells_per_thread"], info["waves_per_reach"]) == (m, w)
+
+
+@pytest.mark.parametrize("shape", ["1,1", "2,1", "8,1", "8,4"])
+def test_table_mode_kernel_shapes(shape, monkeypatch):
+    m, w = map(int, shape.split(","))
+    for name in ("bc_compound_normal", "gerd"):
+        path = os.path.join(GOLDEN, name + ".npz")
+        fx, meta = O.load_fixture(path)
+        if 64 * m * w < meta["N"] - 1:
+            continue
+        run_and_compare(path, "table", shape, monkeypatch)
+
+
+def test_oracle_agreement_on_fresh_inputs():
+    """Seeded inputs that are not in any fixture: HIP path vs CPU oracle (rect channel, N=300)."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    probs = [rect_problem(300, seed=s, n_steps=6) for s in range(5)]
+    with batch_from_problems(probs) as b:
+        b.step(6)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    for i, p in enumerate(probs):
+        out = O.newton_run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL
+        assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL
+        assert np.array_equal(its[:, i], out["iters"])
+
+
+def test_batch_invariance_bitwise():
+    """Reach i inside a mixed batch == reach i alone, bit for bit; chunked stepping == one launch."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    probs = [rect_problem(1000, seed=s, n_steps=4) for s in range(6)]
+    with batch_from_problems(probs) as b:
+        b.step(4)
+        h_all, Q_all = b.history_arrays()
+    for i in (0, 3, 5):
+        with batch_from_problems([probs[i]]) as b1:
+            b1.step(1); b1.step(2); b1.step(1)
+            h1, Q1 = b1.history_arrays()
+        assert np.array_equal(h1[:, 0], h_all[:, i]) and np.array_equal(Q1[:, 0], Q_all[:, i])
+
+
+def test_steady_state_is_a_fixed_point():
+    """Uniform flow at normal depth with constant inflow: one Newton iteration per level, state unchanged
+    (property (v))."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    probs = [rect_problem(4096, seed=s, n_steps=3, steady=True) for s in range(3)]
+    with batch_from_problems(probs, history=False) as b:
+        b.step(3)
+        h, Q = b.state()
+        its = b.iterations()
+        assert np.all(b.status() == 0)
+    for i, p in enumerate(probs):
+        assert np.max(np.abs(h[i] - p.h0)) <= 1e-9 * p.h0[0]
+        assert np.max(np.abs(Q[i] - p.Q0)) <= 1e-9 * p.Q0[0]
+    assert np.all(its[1:] == 1)
+
+
+def test_full_width_reach_against_oracle():
+    """N = 4096 (BASELINE configs[2] node count): 2 reaches x 2 levels against the oracle."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    probs = [rect_problem(4096, seed=s, n_steps=2) for s in (11, 12)]
+    with batch_from_problems(probs) as b:
+        b.step(2)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+        info = b.kernel_info()
+    assert info["waves_per_reach"] == 4 and info["cells_per_thread"] == 16
+    for i, p in enumerate(probs):
+        out = O.newton_run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL
+        assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL
+        assert np.array_equal(its[:, i], out["iters"])
+
+
+def test_max_iter_and_status_reporting():
+    """max_iter exhausted -> status 1 and the level is not advanced (preissmann.py:124-126)."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    p = rect_problem(200, seed=3, n_steps=2)
+    p.max_iter = 1
+    with batch_from_problems([p]) as b:
+        b.step(2)
+        assert b.status()[0] == 1
+        assert b.iterations()[1, 0] == 1
