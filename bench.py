@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""bench.py - reach-timesteps/sec of the batched Preissmann Newton step on MI355X.
+
+    python bench.py --gpus 1 --steps 32 --warmup 4
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"): per GPU 65 536 synthetic rectangular
+reaches x 4 096 nodes, fp64, constant Manning n per reach, upstream flow hydrograph (akbari
+shape), downstream normal depth, steady-state initial condition, theta 0.6, dt 600 s, dx 250 m,
+tolerance 1e-6.  One "step" = one time level (full Newton loop) of every reach in the batch.
+Weak scaling: every rank owns its own block of 65 536 reaches (global reach index seeds the
+draws); the only collective is one RCCL all_gather of the boundary hydrographs, inside the timed
+region.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     - algorithmic HBM bytes of the step kernel / its HIP-event time, vs 8 TB/s
+  cpu_baseline - the numpy/scipy oracle port (oracle/preissmann_oracle.py) on 1 host core on a
+                 bounded sample of the same workload (reported, not the optimisation target)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flow-sim_amd"))
+sys.path.insert(0, ROOT)
+
+SEED = 20260213
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, the unit this kernel actually runs on
+
+
+def c3_reach_parameters(first, count):
+    """SURVEY 8d C3 draws for global reach indices [first, first+count): b, n, S0, Q_base."""
+    rng = np.random.default_rng(SEED)
+    u = rng.random((first + count, 4))[first:]           # same stream as 4 scalar draws per reach
+    b = 50.0 + 250.0 * u[:, 0]
+    n = 0.02 + 0.02 * u[:, 1]
+    S0 = 2e-4 + 8e-4 * u[:, 2]
+    Qb = (50.0 + 450.0 * u[:, 3]) * (b / 100.0)
+    return b, n, S0, Qb
+
+
+def normal_depth_rect(b, n, S0, Q):
+    """Vectorised bisection for Q = K(h) sqrt(S0) in a rectangle (host-side IC, channel.py:296-305)."""
+    lo = np.full_like(b, 1e-9)
+    hi = np.full_like(b, 200.0)
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        A = b * mid
+        P = b + 2 * mid
+        below = A * (A / P) ** (2.0 / 3.0) / n * np.sqrt(S0) < Q
+        lo = np.where(below, mid, lo)
+        hi = np.where(below, hi, mid)
+    return 0.5 * (lo + hi)
+
+
+def inflow_table(Qb, levels, dt):
+    """akbari-shaped hydrograph (cases/akbari_firoozi/settings.py:22-34 form) with Q_p = 2 Q_base."""
+    t = np.arange(levels)[:, None] * dt
+    tp, tb = 5 * 3600.0, 15 * 3600.0
+    Qp = 2.0 * Qb[None, :]
+    rise = Qp / 2 * np.sin(np.pi * t / tp - np.pi / 2) + Qp / 2 + Qb[None, :]
+    fall = Qp / 2 * np.cos(np.pi * (t - tp) / (tb - tp)) + Qp / 2 + Qb[None, :]
+    return np.where(t <= tp, rise, np.where(t <= tb, fall, Qb[None, :]))
+
+
+def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
+    """Oracle port on one host core, same workload definition, bounded sample."""
+    try:
+        import psutil
+        psutil.Process().cpu_affinity([psutil.Process().cpu_affinity()[0]])
+    except Exception:
+        pass
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
+    from oracle import preissmann_oracle as O
+    b, n, S0, Qb = c3_reach_parameters(0, 64)
+    hn = normal_depth_rect(b, n, S0, Qb)
+    steps = 3
+    tgt = inflow_table(Qb, steps + 1, dt)
+    done = 0
+    t0 = time.perf_counter()
+    for r in range(64):
+        geo = {k: np.zeros(N) for k in O.GEO_KEYS}
+        geo["b_main"][:] = b[r]; geo["n_main"][:] = n[r]; geo["n_left"][:] = n[r]; geo["n_right"][:] = n[r]
+        L = (N - 1) * dx
+        geo["z_bed"] = S0[r] * L * (1 - np.arange(N) / (N - 1))
+        p = O.Problem(geo=geo, h0=np.full(N, hn[r]), Q0=np.full(N, Qb[r]),
+                      us=O.BC("flow_hydrograph", bed_level=S0[r] * L, target=tgt[:, r].copy()),
+                      ds=O.BC("normal_depth", bed_level=0.0, bed_slope=float(S0[r])),
+                      theta=theta, dt=dt, dx=dx, nt=steps + 1, tol=tol)
+        O.newton_run(p)
+        done += steps
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": done / el, "unit": "reach-timesteps/s", "cores": 1, "kind": "port",
+            "sample": f"{done // steps} reaches x {N} nodes x {steps} steps, numpy+scipy.spsolve oracle, {el:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU")
+    ap.add_argument("--nodes", type=int, default=4096)
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+
+    import torch
+    import torch.distributed as dist
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    B, N, K, Wm = args.reaches, args.nodes, args.steps, args.warmup
+    theta, dt, dx, tol = 0.6, 600.0, 250.0, 1e-6
+    levels = K + Wm + 1
+    b_, n_, S0, Qb = c3_reach_parameters(rank * B, B)
+    hn = normal_depth_rect(b_, n_, S0, Qb)
+    L = (N - 1) * dx
+
+    batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="rect_uniform", device=local)
+    batch.set_scheme(theta, dt, dx, tol, 100)
+    batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
+    batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
+    batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
+    batch.set_state_uniform(hn, Qb)
+    batch.sync()
+
+    # device view of the hydrograph block for the RCCL gather (zero copy)
+    esz = 8 if args.dtype == "f64" else 4
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": (levels, 4, B), "typestr": "<f8" if esz == 8 else "<f4",
+                                  "data": (batch.hydrograph_device_ptr(), False), "version": 2}
+    hyd_dev = torch.as_tensor(v, device=f"cuda:{local}")
+    gathered = torch.empty((world, K, 4, B), dtype=tdt, device=f"cuda:{local}") if world > 1 else None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        batch.sync()
+
+    if Wm > 0:
+        batch.step(Wm, sync=True)
+    barrier()
+    t0 = time.perf_counter()
+    batch.step(K, sync=False)
+    batch.sync()
+    if world > 1:      # the only exchange of the path: boundary hydrographs of the timed levels
+        dist.all_gather_into_tensor(gathered.view(world * K, 4, B), hyd_dev[Wm + 1:Wm + 1 + K].contiguous())
+    barrier()
+    el = time.perf_counter() - t0
+    kern_ms = batch.last_step_ms()
+
+    st = batch.status()
+    its = batch.iterations(Wm + 1, K)
+    ok = bool(np.all(st == 0))
+    el_t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+    kms_t = torch.tensor([kern_ms], dtype=torch.float64, device=f"cuda:{local}")
+    it_t = torch.tensor([float(its.sum()), float(ok)], dtype=torch.float64, device=f"cuda:{local}")
+    if world > 1:
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kms_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
+    el = float(el_t.item()); kern_ms = float(kms_t.item())
+    info = batch.kernel_info()
+
+    if rank == 0:
+        total = float(B) * K * world
+        real = 8 if args.dtype == "f64" else 4
+        alg_bytes_launch = float(B) * K * (4 * N * real + 8 + 32)      # state in+out, BC target, hydrograph row
+        ach = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
+        mean_its = float(it_t[0].item()) / total
+        out = {
+            "metric": "reach-timesteps/sec (batched Preissmann Newton step)",
+            "value": total / el, "unit": "reach-timesteps/s", "n_gpus": world, "steps": K, "warmup": Wm,
+            "ms_per_step": el * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C3: {B} synthetic rectangular reaches x {N} nodes per GPU, constant Manning n, "
+                                   "flow-hydrograph upstream, normal-depth downstream, theta 0.6, dt 600 s, dx 250 m, tol 1e-6",
+                       "reaches_per_gpu": B, "nodes": N, "parallelism": f"reach-sharded x{world}",
+                       "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
+                       "kernel": info},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "preissmann_step_kernel", "kernel_ms": kern_ms, "launches": 1,
+                         "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
+                         "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -121,6 +121,19 @@ int download(fs_batch *b, double *dst, const void *src, size_t off_elems, size_t
   return 0;
 }
 
+// level 0 of every array from one (h, Q) pair per reach
+template <typename R>
+__global__ void broadcast_state(const R *h, const R *Q, R *hk, R *Qk, R *hg, R *Qg, R *hist_h, R *hist_Q, R *hydro,
+                                size_t B, size_t N) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * N) return;
+  const size_t r = i / N, node = i - r * N;
+  const R hv = h[r], Qv = Q[r];
+  hk[i] = hv; Qk[i] = Qv; hg[i] = hv; Qg[i] = Qv;
+  if (hist_h) { hist_h[i] = hv; hist_Q[i] = Qv; }
+  if (node == 0) { hydro[0 * B + r] = hv; hydro[1 * B + r] = Qv; hydro[2 * B + r] = hv; hydro[3 * B + r] = Qv; }
+}
+
 template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelArgs<R> &a) {
   a.B = b->d.n_reaches; a.N = b->d.n_nodes; a.n_steps = n_steps; a.level0 = b->level; a.max_iter = b->max_iter;
   a.theta = (R)b->theta; a.dt = (R)b->dt; a.dx = (R)b->dx; a.tol = (R)b->tol;
@@ -286,6 +299,31 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->status, 0, B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
+  b->level = 0;
+  b->have_state = true;
+  return 0;
+}
+
+int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q) {
+  if (!b || !h || !Q) return fail("fs_batch_set_state_uniform: null argument");
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes;
+  void *dh = nullptr, *dQ = nullptr;
+  if (upload(b, &dh, h, B) || upload(b, &dQ, Q, B)) return -1;
+  const dim3 grid((unsigned)((B * N + 255) / 256));
+  if (b->d.dtype == FS_F64)
+    hipLaunchKernelGGL((broadcast_state<double>), grid, dim3(256), 0, b->stream, (const double *)dh, (const double *)dQ,
+                       (double *)b->hk, (double *)b->Qk, (double *)b->hg, (double *)b->Qg, (double *)b->hist_h,
+                       (double *)b->hist_Q, (double *)b->hydro, B, N);
+  else
+    hipLaunchKernelGGL((broadcast_state<float>), grid, dim3(256), 0, b->stream, (const float *)dh, (const float *)dQ,
+                       (float *)b->hk, (float *)b->Qk, (float *)b->hg, (float *)b->Qg, (float *)b->hist_h,
+                       (float *)b->hist_Q, (float *)b->hydro, B, N);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemsetAsync(b->status, 0, B * 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
+  HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  hipFree(dh); hipFree(dQ);
   b->level = 0;
   b->have_state = true;
   return 0;

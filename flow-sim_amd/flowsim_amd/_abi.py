@@ -46,6 +46,7 @@ SIGNATURES = {
     "fs_batch_set_geometry_table": (C.c_int, [_P, _D, _D]),
     "fs_batch_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, _D, C.c_int32, C.c_int32, _D]),
     "fs_batch_set_state": (C.c_int, [_P, _D, _D]),
+    "fs_batch_set_state_uniform": (C.c_int, [_P, _D, _D]),
     "fs_batch_step": (C.c_int, [_P, C.c_int32]),
     "fs_batch_sync": (C.c_int, [_P]),
     "fs_batch_level": (C.c_int32, [_P]),

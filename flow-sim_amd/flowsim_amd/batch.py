@@ -119,6 +119,12 @@ class PreissmannBatch:
         Q = np.ascontiguousarray(np.broadcast_to(np.asarray(Q, dtype=np.float64), (self.B, self.N)))
         A.check(self._lib.fs_batch_set_state(self._h, _dptr(h), _dptr(Q)), "set_state")
 
+    def set_state_uniform(self, h, Q):
+        """Steady-state IC of prismatic reaches: one depth and one flow per reach (channel.py:296-305)."""
+        h = np.ascontiguousarray(np.broadcast_to(np.asarray(h, dtype=np.float64), (self.B,)))
+        Q = np.ascontiguousarray(np.broadcast_to(np.asarray(Q, dtype=np.float64), (self.B,)))
+        A.check(self._lib.fs_batch_set_state_uniform(self._h, _dptr(h), _dptr(Q)), "set_state_uniform")
+
     # -- the hot path ---------------------------------------------------------------------
     def step(self, n_steps: int = 1, sync: bool = True):
         A.check(self._lib.fs_batch_step(self._h, int(n_steps)), "step")

@@ -117,6 +117,11 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
  * vector (solver.py:61-63, preissmann.py:48-59).  h, Q: [B][N].  Resets the level counter. */
 int fs_batch_set_state(fs_batch *b, const double *h, const double *Q);
 
+/* Same for the 'steady-state' initial condition of a prismatic reach (channel.py:296-305: one
+ * normal depth and the initial flow at every node): h[B], Q[B], broadcast along the reach on
+ * the device (avoids staging B*N host values for large batches). */
+int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q);
+
 /* THE HOT PATH: advances every reach by n_steps time levels (preissmann.py:108-161).  Results
  * stay on the device: boundary hydrographs, Newton counts, status, (history).  Asynchronous. */
 int fs_batch_step(fs_batch *b, int32_t n_steps);
