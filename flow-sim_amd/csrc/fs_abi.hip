@@ -32,21 +32,25 @@ struct Shape { int M, W; };
 typedef void (*LaunchFn)(const void *args, int B, hipStream_t st);
 typedef const void *KernelPtr;
 
-template <typename R, int SEC, int M, int W> void launch_(const void *args, int B, hipStream_t st) {
+template <typename R, int SEC, int M, int W, bool RAGGED> void launch_(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W>), dim3(B), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
-struct Entry { int dtype, sec, M, W; LaunchFn fn; KernelPtr kp; };
+// full == 1: instantiation without per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
+struct Entry { int dtype, sec, M, W, full; LaunchFn fn; KernelPtr kp; };
 
 #define FS_ENTRY(R, DT, SEC, M, W) \
-  { DT, SEC, M, W, &launch_<R, SEC, M, W>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W> }
+  { DT, SEC, M, W, 0, &launch_<R, SEC, M, W, true>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true> }
+#define FS_ENTRY_FULL(R, DT, SEC, M, W) \
+  { DT, SEC, M, W, 1, &launch_<R, SEC, M, W, false>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, false> }
 
 #define FS_ENTRIES(R, DT)                                                                         \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 2, 1),          \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),          \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 2),        \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4), FS_ENTRY_FULL(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),   \
+  FS_ENTRY_FULL(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),                                                 \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
@@ -60,10 +64,14 @@ const Entry *pick_kernel(int dtype, int sec, int N, std::string *why) {
   const Entry *best = nullptr;
   for (const Entry &e : kEntries) {
     if (e.dtype != dtype || e.sec != sec) continue;
-    if (64 * e.W * e.M < cells) continue;
+    const int cap = 64 * e.W * e.M;
+    if (cap < cells) continue;
+    if (e.full && !(cells == cap || cells == cap - 1)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
-    // smallest capacity first; on ties prefer fewer waves per reach (less cross-wave work)
-    if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W)) best = &e;
+    // smallest capacity first; on ties prefer fewer waves per reach, then the select-free variant
+    if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
+        (e.M == best->M && e.W == best->W && e.full > best->full))
+      best = &e;
   }
   if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4097 nodes)";
   return best;

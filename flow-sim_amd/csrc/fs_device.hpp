@@ -284,6 +284,77 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
   return r;
 }
 
+// Rectangular prismatic reaches: same rows with the closed-form conveyance of node_terms_rect and
+// no out-of-line call (a call inside the Newton loop makes the caller spill its register-resident
+// state around it).  zsec = bed level of the boundary node's section.
+template <typename R>
+__device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach, int B, int level, R b, R n, R zsec,
+                                                 R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
+  BCRow<R> r;
+  auto p = [&](int i) { return bc_param(bc, i, reach, B); };
+  switch (bc.kind) {
+    case FS_BC_FLOW_HYDROGRAPH:
+      r.res = Q - bc.target[(size_t)level * B + reach]; r.dh = R(0); r.dq = R(1); break;
+    case FS_BC_STAGE_HYDROGRAPH:
+      r.res = h - (bc.target[(size_t)level * B + reach] - p(0)); r.dh = R(1); r.dq = R(0); break;
+    case FS_BC_FIXED_DEPTH:
+      r.res = h - p(0); r.dh = R(1); r.dq = R(0); break;
+    case FS_BC_NORMAL_DEPTH: {
+      const R S0 = p(0), bed = p(1);
+      const R sg = S0 < R(0) ? R(-1) : R(1);
+      const R rt = sqrt_(fabs_(S0));
+      // K = A R^(2/3) / n ; dK/dA * T = K (1 + (2/3) b/P) / h        (rectangle)
+      const R P = __builtin_fma(R(2), h, b);
+      const R Rh = b * h * frcp(P);
+      const R K = b * h * Rh * rcbrt_pos(Rh) / n;
+      const R hd = h + bed - zsec;                                      // df_dh uses hw = h + bed_level
+      const R Pd = __builtin_fma(R(2), hd, b);
+      const R rPd = frcp(Pd);
+      const R Rd = b * hd * rPd;
+      const R Kd = b * hd * Rd * rcbrt_pos(Rd) / n;
+      r.res = Q - sg * K * rt;
+      r.dh = R(0) - sg * rt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) / hd;
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_POWER: {
+      const R x = p(3) + h + p(2);
+      r.res = Q - p(0) * pow_(x, p(1));
+      r.dh = R(0) - p(0) * p(1) * pow_(x, p(1) - R(1));
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_POLY: {
+      const R x = p(4) + h + p(3);
+      r.res = Q - (p(0) * x * x + p(1) * x + p(2));
+      r.dh = R(0) - (p(0) * R(2) * x + p(1));
+      r.dq = R(1);
+    } break;
+    case FS_BC_RATING_BLEND: {
+      const R z = p(9) + h, dY = p(8);
+      const R q0 = rating_blend(z, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      const R qp = rating_blend(z + dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      const R qm = rating_blend(z - dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
+      r.res = Q - q0;
+      r.dh = R(0) - (qp - qm) / (R(2) * dY);
+      r.dq = R(1);
+    } break;
+    case FS_BC_STORAGE: {
+      const R area = p(0), ymin = p(1), bed = p(4);
+      const R vol = R(0.5) * (Qold + Q) * dt;
+      const R Yold = level == 1 ? h + bed : Yprev;
+      R Y = Yold + vol / area;
+      if (!(Y >= p(2) && Y <= p(3))) *flag = FS_STORAGE_RANGE;
+      if (Y < ymin) Y = ymin;
+      *Ynew = Y;
+      r.res = h - (Y - bed);
+      r.dh = R(1);
+      r.dq = R(0) - (Y <= ymin ? R(0) : R(1) / area) * R(0.5) * dt;
+    } break;
+    default:
+      r.res = R(0); r.dh = R(1); r.dq = R(0); break;
+  }
+  return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // segment algebra: a "segment" is the pair of linear relations left between the first and the
 // last node of a run of cells once the interior nodes are eliminated,

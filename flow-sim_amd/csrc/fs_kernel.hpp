@@ -17,7 +17,9 @@
 //     (preissmann.py:166-177; SURVEY F2: it is the pre-update iterate) and read back only by the
 //     next launch.  Boundary hydrographs and iteration counts go to small per-level tables.
 //
-// Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach.
+// Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
+// RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
+// padding and the per-cell padding selects (and their 64-bit lane masks) disappear.
 #pragma once
 #include "fs_device.hpp"
 
@@ -61,11 +63,9 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
     return z_us * (R(1) - w2) + z_ds * w2;
   }
   __device__ __forceinline__ NodeTerms<R> terms(int, R h, R Q) const { return node_terms_rect(b, rb, n, h, Q); }
-  __device__ __forceinline__ SecParams<R> section(int node) const {
-    SecParams<R> s;
-    s.z = bed(node); s.b = b; s.m = R(0); s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
-    s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
-    return s;
+  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
+                                               R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    return bc_eval_rect(bc, reach, B, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -99,6 +99,10 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
     return node_terms_general(section(node), h, Q);
   }
+  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
+                                               R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+  }
 };
 
 // LDS carve-up for one reach
@@ -113,12 +117,13 @@ template <typename R, int M, int W> struct Smem {
 };
 
 // What back-substitution needs for an interior node j of a lane's chunk: the M-like row of the
-// running segment [first node .. j] (sm, pm, qm), 1/det of the pivot block and the continuity
-// right-hand side of cell j.  The continuity coefficients themselves (T_j/(2dt), -+theta/dx) are
-// recomputed.
-template <typename R> struct LocalElim { R r, sm0, sm1, pm0, pm1, qm, qc; };
+// running segment [first node .. j] (sm, pm, qm), pre-scaled by 1/det of the pivot block.  The
+// continuity row of cell j that completes the block (T_j/(2dt), -+theta/dx and its residual) is
+// recomputed from the still un-updated state when the top width is constant (kConstT), else its
+// residual is kept in qc.
+template <typename R> struct LocalElim { R rs0, rs1, rp0, rp1, rq, qc; };
 
-template <typename R, int SEC, int M, int W>
+template <typename R, int SEC, int M, int W, bool RAGGED = true>
 __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
@@ -160,7 +165,6 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       sm.kc[2][c][t] = hthk * sumA;
       sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (L.Se + Rn.Se);
       L = Rn;
-      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -218,7 +222,8 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
           if (!Geo::kConstT) Tn[c + 1] = Rn.T;
           Seg<R> cell;
           {
-            const bool real = s0 + c < NC;       // else identity padding: d_{i+1} = d_i
+            // identity padding d_{i+1} = d_i beyond the last cell
+            const bool real = (RAGGED || c == M - 1) ? (s0 + c < NC) : true;
             const R sumA = L.A + Rn.A;
             const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + kcb[(0 * M + c) * T];          // :220-249
             const R avgA = hth * sumA + kcb[(2 * M + c) * T];
@@ -243,7 +248,8 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
             const R det = seg.sm0 * cell.pc1 - seg.sm1 * cell.pc0;
             const R r = frcp(det);
             LocalElim<R> &e = el[c - 1];
-            e.r = r; e.sm0 = seg.sm0; e.sm1 = seg.sm1; e.pm0 = seg.pm0; e.pm1 = seg.pm1; e.qm = seg.qm; e.qc = cell.qc;
+            e.rs0 = r * seg.sm0; e.rs1 = r * seg.sm1; e.rp0 = r * seg.pm0; e.rp1 = r * seg.pm1; e.rq = r * seg.qm;
+            if (!Geo::kConstT) e.qc = cell.qc;
             const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
             const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
             const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
@@ -257,14 +263,13 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
             seg = o;
           }
           L = Rn;
-          __builtin_amdgcn_sched_barrier(0);   // keep the schedule cell by cell: bounded live ranges
         }
       }
 
       // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
-        const BCRow<R> U = bc_eval(a.us, reach, a.B, level, geo.section(0), h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        const BCRow<R> U = geo.boundary(a.us, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
         sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
         nrm2 += U.res * U.res;
       }
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         int flag = 0;
 #pragma unroll
         for (int j = 1; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        const BCRow<R> Dn = bc_eval(a.ds, reach, a.B, level, geo.section(N - 1), hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        const BCRow<R> Dn = geo.boundary(a.ds, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
         nrm2 += Dn.res * Dn.res;
         if (flag) sm.xflag[parity] = flag;
@@ -389,25 +394,36 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       R dL0 = shfl_up_(dR0, 1), dL1 = shfl_up_(dR1, 1);
       if (lane == 0) { dL0 = bL0; dL1 = bL1; }
 
-      R n0 = dR0, n1 = dR1;
-      h[M] += dR0; Q[M] += dR1;
+      R n0 = dR0, n1 = dR1;         // update of node j+1, applied once its old value is no longer needed
+      if (Geo::kConstT) {
+        // The continuity residuals are recomputed below on purpose (one value per node less to keep
+        // across the solve).  Hide the operands so that common-subexpression elimination does not
+        // resurrect the fold's copies of dQ / kc0 and keep 2 values per node alive instead.
+        asm volatile("" : "+v"(kcb));
+#pragma unroll
+        for (int j = 0; j <= M; ++j) asm volatile("" : "+v"(h[j]), "+v"(Q[j]));
+      }
 #pragma unroll
       for (int j = M - 1; j >= 1; --j) {
         const LocalElim<R> &e = el[j - 1];
         // pivot block rows: (sm0, sm1) and the continuity row of cell j: (T_j/(2dt), -cq | T_{j+1}/(2dt), cq)
-        const R pc0 = (Geo::kConstT ? geo.terms_T() : Tn[j]) * r2dt;
-        const R sc0 = (Geo::kConstT ? geo.terms_T() : Tn[j + 1]) * r2dt;
-        const bool real = s0 + j < NC;      // cell j is a real cell (else identity padding)
-        const R c0 = real ? pc0 : R(1), c1 = real ? -cq : R(0);
-        const R b0 = real ? sc0 : R(-1), b1 = real ? cq : R(0);
-        const R sig = e.qm - (e.pm0 * dL0 + e.pm1 * dL1);
-        const R tau = e.qc - (b0 * n0 + b1 * n1);
-        const R d0 = e.r * (c1 * sig - e.sm1 * tau);
-        const R d1 = e.r * (e.sm0 * tau - c0 * sig);
-        h[j] += d0; Q[j] += d1;
-        n0 = d0; n1 = d1;
-        __builtin_amdgcn_sched_barrier(0);
+        const bool real = (RAGGED || j == M - 1) ? (s0 + j < NC) : true;   // else identity padding
+        R c0, b0, qc;
+        if (Geo::kConstT) {
+          c0 = geo.terms_T() * r2dt; b0 = c0;
+          qc = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
+        } else {
+          c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc;
+        }
+        h[j + 1] += n0; Q[j + 1] += n1;
+        const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
+        if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
+        const R rsig = e.rq - (e.rp0 * dL0 + e.rp1 * dL1);
+        const R tau = qc - (b0 * n0 + b1 * n1);
+        n0 = c1 * rsig - e.rs1 * tau;
+        n1 = e.rs0 * tau - c0 * rsig;
       }
+      h[1] += n0; Q[1] += n1;
       h[0] += dL0; Q[0] += dL1;                                        // preissmann.py:146-147
     }
     if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
