@@ -32,32 +32,42 @@ struct Shape { int M, W; };
 typedef void (*LaunchFn)(const void *args, int B, hipStream_t st);
 typedef const void *KernelPtr;
 
-template <typename R, int SEC, int M, int W, bool RAGGED> void launch_(const void *args, int B, hipStream_t st) {
+template <typename R, int SEC, int M, int W, bool RAGGED, bool BCFAST>
+void launch_(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED>), dim3(B), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCFAST>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
-// full == 1: instantiation without per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
-struct Entry { int dtype, sec, M, W, full; LaunchFn fn; KernelPtr kp; };
+// full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
+// bcfast == 1: boundary rows inlined, valid only for RECT_UNIFORM with bc_is_light() kinds on both ends
+struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
 
-#define FS_ENTRY(R, DT, SEC, M, W) \
-  { DT, SEC, M, W, 0, &launch_<R, SEC, M, W, true>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true> }
-#define FS_ENTRY_FULL(R, DT, SEC, M, W) \
-  { DT, SEC, M, W, 1, &launch_<R, SEC, M, W, false>, (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, false> }
+#define FS_ENTRY_X(R, DT, SEC, M, W, FULL, FAST)                        \
+  { DT, SEC, M, W, FULL, FAST, &launch_<R, SEC, M, W, !(FULL), FAST>,   \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), FAST> }
+#define FS_ENTRY(R, DT, SEC, M, W) FS_ENTRY_X(R, DT, SEC, M, W, 0, false)
 
 #define FS_ENTRIES(R, DT)                                                                         \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 2, 1),          \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),          \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 2),        \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4), FS_ENTRY_FULL(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),   \
-  FS_ENTRY_FULL(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),                                                 \
+  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),   \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),                                          \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
 
+#ifdef FS_MINIMAL   // experiment builds: just the flagship shapes
+const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
+#else
 const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32)};
+#endif
 
-const Entry *pick_kernel(int dtype, int sec, int N, std::string *why) {
+const Entry *pick_kernel(int dtype, int sec, int N, bool light_bc, std::string *why) {
   const int cells = N - 1;
   int wantM = 0, wantW = 0;
   if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
@@ -67,10 +77,11 @@ const Entry *pick_kernel(int dtype, int sec, int N, std::string *why) {
     const int cap = 64 * e.W * e.M;
     if (cap < cells) continue;
     if (e.full && !(cells == cap || cells == cap - 1)) continue;
+    if (e.bcfast && !light_bc) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the select-free variant
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
-        (e.M == best->M && e.W == best->W && e.full > best->full))
+        (e.M == best->M && e.W == best->W && e.full + e.bcfast > best->full + best->bcfast))
       best = &e;
   }
   if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4097 nodes)";
@@ -186,7 +197,7 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     return nullptr;
   }
   std::string why;
-  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, &why);
+  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, true, &why);
   if (!k) { fail("fs_batch_create: " + why); return nullptr; }
   fs_batch *b = new fs_batch();
   b->d = *desc;
@@ -344,6 +355,12 @@ int fs_batch_step(fs_batch *b, int32_t n_steps) {
   if (n_steps < 1) return fail("fs_batch_step: n_steps must be >= 1");
   if (b->level + n_steps >= b->d.max_levels) return fail("fs_batch_step: would run past max_levels");
   HIP_TRY(hipSetDevice(b->d.device));
+  {   // the boundary kinds are known now: prefer the variant with inlined boundary rows
+    const bool light = fs::bc_is_light(b->bc_kind[0]) && fs::bc_is_light(b->bc_kind[1]);
+    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, light, nullptr);
+    if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
+    b->kern = k;
+  }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   if (b->d.dtype == FS_F64) {
     fs::KernelArgs<double> a; fill_args(b, n_steps, a);

@@ -52,6 +52,53 @@ __device__ __forceinline__ float rcbrt_pos(float x) {
   return __builtin_fmaf(y * (1.0f / 3.0f), e, y);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Explicit AGPR residency.  gfx950 has a unified 512-entry register file per lane but VALU
+// operands must be architectural VGPRs (256); the other half is reachable only through
+// v_accvgpr_read/write.  Values that are written once per Newton iteration and read once much
+// later (the per-node elimination records) are parked there on purpose with the "a" inline-asm
+// register class instead of leaving the choice to the spiller (which sends the overflow to
+// scratch memory once both halves are full).
+// ---------------------------------------------------------------------------------------------
+#ifndef FS_PARK
+#define FS_PARK 0   // measured: letting the register allocator place these beats forcing AGPRs
+#endif
+template <typename R> struct Parked;
+#if !FS_PARK
+template <typename R> struct Parked {
+  R v;
+  __device__ __forceinline__ void put(R x) { v = x; }
+  __device__ __forceinline__ R get() const { return v; }
+};
+#else
+template <> struct Parked<double> {
+  uint32_t lo, hi;
+  __device__ __forceinline__ void put(double v) {
+    const uint32_t l = (uint32_t)__double2loint(v), h = (uint32_t)__double2hiint(v);
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(lo) : "v"(l));
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(hi) : "v"(h));
+  }
+  __device__ __forceinline__ double get() const {
+    uint32_t l, h;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(l) : "a"(lo));
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(h) : "a"(hi));
+    return __hiloint2double((int)h, (int)l);
+  }
+};
+template <> struct Parked<float> {
+  uint32_t w;
+  __device__ __forceinline__ void put(float v) {
+    const uint32_t x = __float_as_uint(v);
+    asm("v_accvgpr_write_b32 %0, %1" : "=a"(w) : "v"(x));
+  }
+  __device__ __forceinline__ float get() const {
+    uint32_t x;
+    asm("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(w));
+    return __uint_as_float(x);
+  }
+};
+#endif
+
 template <typename R> __device__ __forceinline__ R fabs_(R x) { return x < R(0) ? -x : x; }
 template <typename R> __device__ __forceinline__ R fmax_(R a, R b) { return a > b ? a : b; }
 __device__ __forceinline__ double pow_(double a, double b) { return pow(a, b); }
@@ -286,7 +333,11 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
 
 // Rectangular prismatic reaches: same rows with the closed-form conveyance of node_terms_rect and
 // no out-of-line call (a call inside the Newton loop makes the caller spill its register-resident
-// state around it).  zsec = bed level of the boundary node's section.
+// state around it).  Only the kinds that need no pow() are inlined (bc_is_light): the power rating
+// curve drags ~50 SGPR constants and ~300 instructions of pow() into the hot loop otherwise.
+// zsec = bed level of the boundary node's section.
+__host__ __device__ inline bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER; }
+
 template <typename R>
 __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach, int B, int level, R b, R n, R zsec,
                                                  R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
@@ -306,20 +357,15 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach,
       // K = A R^(2/3) / n ; dK/dA * T = K (1 + (2/3) b/P) / h        (rectangle)
       const R P = __builtin_fma(R(2), h, b);
       const R Rh = b * h * frcp(P);
-      const R K = b * h * Rh * rcbrt_pos(Rh) / n;
+      const R rn = frcp(n);
+      const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
       const R hd = h + bed - zsec;                                      // df_dh uses hw = h + bed_level
       const R Pd = __builtin_fma(R(2), hd, b);
       const R rPd = frcp(Pd);
       const R Rd = b * hd * rPd;
-      const R Kd = b * hd * Rd * rcbrt_pos(Rd) / n;
+      const R Kd = b * hd * Rd * rcbrt_pos(Rd) * rn;
       r.res = Q - sg * K * rt;
-      r.dh = R(0) - sg * rt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) / hd;
-      r.dq = R(1);
-    } break;
-    case FS_BC_RATING_POWER: {
-      const R x = p(3) + h + p(2);
-      r.res = Q - p(0) * pow_(x, p(1));
-      r.dh = R(0) - p(0) * p(1) * pow_(x, p(1) - R(1));
+      r.dh = R(0) - sg * rt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) * frcp(hd);
       r.dq = R(1);
     } break;
     case FS_BC_RATING_POLY: {

@@ -19,9 +19,21 @@
 //
 // Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
 // RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
-// padding and the per-cell padding selects (and their 64-bit lane masks) disappear.
+// padding and the per-cell padding selects (and their 64-bit lane masks) disappear;
+// BCFAST = true (RECT_UNIFORM only) inlines the boundary rows and requires bc_is_light() kinds.
 #pragma once
 #include "fs_device.hpp"
+
+// build-time experiment switches (defaults = the configuration that measured fastest)
+#ifndef FS_SKEW
+#define FS_SKEW 0
+#endif
+#ifndef FS_CELL_FENCE
+#define FS_CELL_FENCE 1
+#endif
+#ifndef FS_LAUNDER_BACK
+#define FS_LAUNDER_BACK 1
+#endif
 
 namespace fs {
 
@@ -63,9 +75,18 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
     return z_us * (R(1) - w2) + z_ds * w2;
   }
   __device__ __forceinline__ NodeTerms<R> terms(int, R h, R Q) const { return node_terms_rect(b, rb, n, h, Q); }
+  __device__ __forceinline__ SecParams<R> section(int node) const {
+    SecParams<R> s;
+    s.z = bed(node); s.b = b; s.m = R(0); s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
+    s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
+    return s;
+  }
+  template <bool BCFAST>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    return bc_eval_rect(bc, reach, B, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
+    if (BCFAST)
+      return bc_eval_rect(bc, reach, B, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -99,6 +120,7 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
     return node_terms_general(section(node), h, Q);
   }
+  template <bool BCFAST>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
     return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
@@ -121,9 +143,9 @@ template <typename R, int M, int W> struct Smem {
 // continuity row of cell j that completes the block (T_j/(2dt), -+theta/dx and its residual) is
 // recomputed from the still un-updated state when the top width is constant (kConstT), else its
 // residual is kept in qc.
-template <typename R> struct LocalElim { R rs0, rs1, rp0, rp1, rq, qc; };
+template <typename R> struct LocalElim { Parked<R> rs0, rs1, rp0, rp1, rq, qc; };   // lives in AGPRs
 
-template <typename R, int SEC, int M, int W, bool RAGGED = true>
+template <typename R, int SEC, int M, int W, bool RAGGED = true, bool BCFAST = false>
 __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
@@ -206,9 +228,82 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
       parity ^= 1;
 
+      // opaque lane offset (an integer, so the accesses stay LDS ds_read, not flat): the 4*M level
+      // constants are Newton-loop invariants and would otherwise be hoisted into registers
+      int kco = t;
+      asm volatile("" : "+v"(kco));
+      const R *kcb = &sm.kc[0][0][0] + kco;
+
+#if FS_SKEW
       // ================= 1. local assembly + fold (registers only) =================
-      const R *kcb = &sm.kc[0][0][t];
-      asm volatile("" : "+v"(kcb));        // opaque: no hoisting of the 4*M loads out of the Newton loop
+      // Software-pipelined by one cell: block c assembles cell c (independent work: two reciprocals,
+      // an x^(-1/3), ~45 flops) next to the merge of cell c-1 into the running segment (the serial
+      // chain).  Each cell sits in its own basic block behind an always-true uniform branch the
+      // compiler cannot fold: instruction selection works per block, so the M cells keep their
+      // order instead of being re-sorted into "all coefficients first, merge chain last" with 10*M
+      // values parked in between.
+      LocalElim<R> el[M > 1 ? M - 1 : 1];
+      R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
+      Seg<R> seg, pend;
+      R nrm2 = R(0);
+      {
+        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+        if (!Geo::kConstT) Tn[0] = L.T;
+#pragma unroll
+        for (int c = 0; c <= M; ++c) {
+          if (a.level0 > c - 65536) {            // opaque, uniform, always true
+            if (c >= 2) {
+              // merge(seg, pend): pend is cell c-1, the shared node is local node c-1
+              const R det = seg.sm0 * pend.pc1 - seg.sm1 * pend.pc0;
+              const R r = frcp(det);
+              LocalElim<R> &e = el[c - 2];
+              e.rs0.put(r * seg.sm0); e.rs1.put(r * seg.sm1); e.rp0.put(r * seg.pm0); e.rp1.put(r * seg.pm1);
+              e.rq.put(r * seg.qm);
+              if (!Geo::kConstT) e.qc.put(pend.qc);
+              const R w10 = pend.pc1 * r, w11 = -pend.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
+              const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
+              const R ga = pend.pm0 * w10 + pend.pm1 * w11, ep = pend.pm0 * w20 + pend.pm1 * w21;
+              Seg<R> o;
+              o.pc0 = seg.pc0 - al * seg.pm0; o.pc1 = seg.pc1 - al * seg.pm1;
+              o.sc0 = -be * pend.sc0;         o.sc1 = -be * pend.sc1;
+              o.qc = seg.qc - al * seg.qm - be * pend.qc;
+              o.pm0 = -ga * seg.pm0;          o.pm1 = -ga * seg.pm1;
+              o.sm0 = pend.sm0 - ep * pend.sc0; o.sm1 = pend.sm1 - ep * pend.sc1;
+              o.qm = pend.qm - ga * seg.qm - ep * pend.qc;
+              seg = o;
+            } else if (c == 1) {
+              seg = pend;
+            }
+            if (c < M) {
+              const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+              if (!Geo::kConstT) Tn[c + 1] = Rn.T;
+              // identity padding d_{i+1} = d_i beyond the last cell
+              const bool real = (RAGGED || c == M - 1) ? (s0 + c < NC) : true;
+              const R sumA = L.A + Rn.A;
+              const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + kcb[(0 * M + c) * T];          // :220-249
+              const R avgA = hth * sumA + kcb[(2 * M + c) * T];
+              const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + kcb[(3 * M + c) * T];
+              const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + kcb[(1 * M + c) * T] +
+                             g * avgA * S;                                                     // :251-301
+              nrm2 += real ? Cres * Cres + Mres * Mres : R(0);
+              const R gA = g * avgA, gS = g * hth * S;
+              pend.pc0 = real ? L.T * r2dt : R(1);   pend.pc1 = real ? -cq : R(0);             // :431-447, :476-491
+              pend.sc0 = real ? Rn.T * r2dt : R(-1); pend.sc1 = real ? cq : R(0);              // :407-422, :456-471
+              pend.qc = real ? -Cres : R(0);
+              pend.pm0 = real ? cq * L.v * L.v * L.T + gA * (hth * L.eA - cq) + gS * L.T : R(0);        // :558-612
+              pend.pm1 = real ? r2dt - cq * R(2) * L.v + gA * hth * L.eQ : R(1);                         // :677-733
+              pend.sm0 = real ? -cq * Rn.v * Rn.v * Rn.T + gA * (hth * Rn.eA + cq) + gS * Rn.T : R(0);  // :496-550
+              pend.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
+              pend.qm = real ? -Mres : R(0);
+              L = Rn;
+            }
+          }
+        }
+        if (M == 1) seg = pend;
+      }
+
+#else
+      // ================= 1. local assembly + fold (registers only) =================
       LocalElim<R> el[M > 1 ? M - 1 : 1];
       R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
       Seg<R> seg;
@@ -248,8 +343,9 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
             const R det = seg.sm0 * cell.pc1 - seg.sm1 * cell.pc0;
             const R r = frcp(det);
             LocalElim<R> &e = el[c - 1];
-            e.rs0 = r * seg.sm0; e.rs1 = r * seg.sm1; e.rp0 = r * seg.pm0; e.rp1 = r * seg.pm1; e.rq = r * seg.qm;
-            if (!Geo::kConstT) e.qc = cell.qc;
+            e.rs0.put(r * seg.sm0); e.rs1.put(r * seg.sm1); e.rp0.put(r * seg.pm0); e.rp1.put(r * seg.pm1);
+            e.rq.put(r * seg.qm);
+            if (!Geo::kConstT) e.qc.put(cell.qc);
             const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
             const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
             const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
@@ -263,13 +359,17 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
             seg = o;
           }
           L = Rn;
+#if FS_CELL_FENCE
+          __builtin_amdgcn_sched_barrier(0);
+#endif
         }
       }
 
+#endif
       // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
-        const BCRow<R> U = geo.boundary(a.us, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        const BCRow<R> U = geo.template boundary<BCFAST>(a.us, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
         sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
         nrm2 += U.res * U.res;
       }
@@ -278,7 +378,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         int flag = 0;
 #pragma unroll
         for (int j = 1; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        const BCRow<R> Dn = geo.boundary(a.ds, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        const BCRow<R> Dn = geo.template boundary<BCFAST>(a.ds, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
         nrm2 += Dn.res * Dn.res;
         if (flag) sm.xflag[parity] = flag;
@@ -395,11 +495,12 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       if (lane == 0) { dL0 = bL0; dL1 = bL1; }
 
       R n0 = dR0, n1 = dR1;         // update of node j+1, applied once its old value is no longer needed
-      if (Geo::kConstT) {
+      if (Geo::kConstT && FS_LAUNDER_BACK) {
         // The continuity residuals are recomputed below on purpose (one value per node less to keep
         // across the solve).  Hide the operands so that common-subexpression elimination does not
         // resurrect the fold's copies of dQ / kc0 and keep 2 values per node alive instead.
-        asm volatile("" : "+v"(kcb));
+        asm volatile("" : "+v"(kco));
+        kcb = &sm.kc[0][0][0] + kco;
 #pragma unroll
         for (int j = 0; j <= M; ++j) asm volatile("" : "+v"(h[j]), "+v"(Q[j]));
       }
@@ -413,15 +514,15 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
           c0 = geo.terms_T() * r2dt; b0 = c0;
           qc = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
         } else {
-          c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc;
+          c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc.get();
         }
         h[j + 1] += n0; Q[j + 1] += n1;
         const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
         if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
-        const R rsig = e.rq - (e.rp0 * dL0 + e.rp1 * dL1);
+        const R rsig = e.rq.get() - (e.rp0.get() * dL0 + e.rp1.get() * dL1);
         const R tau = qc - (b0 * n0 + b1 * n1);
-        n0 = c1 * rsig - e.rs1 * tau;
-        n1 = e.rs0 * tau - c0 * rsig;
+        n0 = c1 * rsig - e.rs1.get() * tau;
+        n1 = e.rs0.get() * tau - c0 * rsig;
       }
       h[1] += n0; Q[1] += n1;
       h[0] += dL0; Q[0] += dL1;                                        // preissmann.py:146-147

@@ -75,7 +75,7 @@ def lib():
     """Loads libflowsim_hip.so (once).  Raises FlowsimError if it has not been built."""
     global _lib
     if _lib is None:
-        path = os.path.normpath(LIB_PATH)
+        path = os.path.normpath(os.environ.get("FS_LIB", LIB_PATH))     # FS_LIB: experiment builds
         if not os.path.exists(path):
             raise FlowsimError(
                 f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; "
