@@ -79,13 +79,13 @@ def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
         pass
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import preissmann_oracle as O
-    b, n, S0, Qb = c3_reach_parameters(0, 64)
+    b, n, S0, Qb = c3_reach_parameters(0, 1024)
     hn = normal_depth_rect(b, n, S0, Qb)
-    steps = 3
+    steps = 4
     tgt = inflow_table(Qb, steps + 1, dt)
     done = 0
     t0 = time.perf_counter()
-    for r in range(64):
+    for r in range(1024):
         geo = {k: np.zeros(N) for k in O.GEO_KEYS}
         geo["b_main"][:] = b[r]; geo["n_main"][:] = n[r]; geo["n_left"][:] = n[r]; geo["n_right"][:] = n[r]
         L = (N - 1) * dx
@@ -192,6 +192,10 @@ def main():
     if rank == 0:
         total = float(B) * K * world
         real = 8 if args.dtype == "f64" else 4
+        traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload shape)
+        tj = os.path.join(ROOT, "profiles", "round1", "hbm_traffic.json")
+        if os.path.exists(tj) and N == 4096 and args.dtype == "f64":
+            traffic = json.load(open(tj))["hbm_bytes_per_reach_timestep"] * float(B) * K
         alg_bytes_launch = float(B) * K * (4 * N * real + 8 + 32)      # state in+out, BC target, hydrograph row
         ach = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
         mean_its = float(it_t[0].item()) / total
@@ -206,7 +210,8 @@ def main():
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
                        "kernel": info},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/round1/hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, per reach-timestep x units of this launch)",
                          "kernel": "preissmann_step_kernel", "kernel_ms": kern_ms, "launches": 1,
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
                          "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},

@@ -62,6 +62,8 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
 #ifdef FS_MINIMAL   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
 #else
 const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32)};
@@ -108,7 +110,7 @@ struct fs_batch {
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
   void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
-  void *Yprev = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
+  void *Yprev = nullptr, *stage_hist = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
   int32_t *iters = nullptr, *status = nullptr;
 };
 
@@ -164,7 +166,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
     bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
     bc[s]->params = (const R *)b->bc_params[s]; bc[s]->target = (const R *)b->bc_target[s];
   }
-  a.Yprev = (R *)b->Yprev; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
+  a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
 }
 
@@ -221,6 +223,8 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc((void **)&b->iters, L * B * 4)) != hipSuccess) return bad("hipMalloc(iters)", e);
   if ((e = hipMalloc((void **)&b->status, B * 4)) != hipSuccess) return bad("hipMalloc(status)", e);
   if ((e = hipMalloc(&b->Yprev, B * b->esz)) != hipSuccess) return bad("hipMalloc(Yprev)", e);
+  if ((e = hipMalloc(&b->stage_hist, L * B * b->esz)) != hipSuccess) return bad("hipMalloc(stage_hist)", e);
+  hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream);
   if (desc->flags & FS_FLAG_HISTORY) {
     if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
     if ((e = hipMalloc(&b->hist_Q, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
@@ -237,7 +241,7 @@ void fs_batch_destroy(fs_batch *b) {
   if (!b) return;
   if (b->stream) hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
-                  b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->hydro, b->hist_h, b->hist_Q,
+                  b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status};
   for (void *p : bufs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -430,6 +434,13 @@ int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, doubl
 int fs_batch_get_storage_stage(fs_batch *b, double *out) {
   if (!b || !out) return fail("fs_batch_get_storage_stage: null argument");
   return download(b, out, b->Yprev, 0, b->d.n_reaches);
+}
+
+int fs_batch_get_storage_stages(fs_batch *b, int32_t first, int32_t n, double *out) {
+  if (!b || !out) return fail("fs_batch_get_storage_stages: null argument");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_storage_stages: level range out of bounds");
+  const size_t B = b->d.n_reaches;
+  return download(b, out, b->stage_hist, (size_t)first * B, (size_t)n * B);
 }
 
 void *fs_batch_hydrograph_device_ptr(fs_batch *b) { return b ? b->hydro : nullptr; }

@@ -47,6 +47,7 @@ template <typename R> struct KernelArgs {
   const R *n_override;     // TABLE: [B] or nullptr
   BCDesc<R> us, ds;
   R *Yprev;                // [B] storage stage of the current level
+  R *stage_hist;           // [levels][B] storage stage per level (boundary.py:126-131)
   R *hydro;                // [levels][4][B]
   int32_t *iters;          // [levels][B]
   int32_t *status;         // [B]
@@ -469,6 +470,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
               a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
             }
           Yprev = Ynew;
+          if (a.ds.kind == FS_BC_STORAGE) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
         }
       }
 

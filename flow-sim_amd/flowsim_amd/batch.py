@@ -180,6 +180,13 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_get_storage_stage(self._h, _dptr(out)), "get_storage_stage")
         return out
 
+    def storage_stages(self, first=0, n=None):
+        """[n, B] reservoir stage per time level (storage boundary only)."""
+        n = self.level + 1 - first if n is None else n
+        out = np.empty((n, self.B))
+        A.check(self._lib.fs_batch_get_storage_stages(self._h, first, n, _dptr(out)), "get_storage_stages")
+        return out
+
     def last_step_ms(self):
         return self._lib.fs_batch_last_step_ms(self._h)
 

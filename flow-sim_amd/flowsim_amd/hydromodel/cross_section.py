@@ -1,0 +1,264 @@
+"""Cross-sections on the host: the trapezoid family of the reference
+(src/hydromodel/cross_section.py:549-846) and the distance-weighted interpolation between two
+sections (cross_section.py:857-930).
+
+Geometry is kept as plain parameter records; `section_table()` turns a list of sections into the
+[param][node] structure-of-arrays block the kernel reads (include/flowsim_abi.h, FS_GEO_*), and
+`props()` evaluates area / perimeter / top width / conveyance for whole arrays of nodes at once -
+used for initial conditions and post-processing, never inside the Newton loop.
+
+IrregularSection (polyline sections) is SURVEY.md 8(f) rank 2 and not provided yet.
+"""
+from abc import ABC, abstractmethod
+
+import numpy as np
+from scipy.optimize import brentq
+
+from . import hydraulics
+
+GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
+            "b_fp_l", "b_fp_r", "m_fp", "curvature")
+
+
+def props(geo, hw):
+    """A, P, R, T at water level(s) hw for parameter arrays `geo` (cross_section.py:623-679).
+    Over bank the total area leaves out the column above the main channel while the top width
+    keeps it - the reference's behaviour, reproduced on purpose."""
+    z, b, m = geo["z_bed"], geo["b_main"], geo["m_main"]
+    d = np.maximum(0.0, hw - z)
+    T = b + 2.0 * m * d
+    A = (b + T) / 2.0 * d
+    P = b + 2.0 * d * np.sqrt(1.0 + m * m)
+    over = (geo["is_compound"] > 0.5) & (d > geo["h_bf"])
+    if np.any(over):
+        hb, mf = geo["h_bf"], geo["m_fp"]
+        dfp = d - hb
+        Tb = b + 2.0 * m * hb
+        sf = np.sqrt(1.0 + mf * mf)
+        A_o = (b + Tb) / 2.0 * hb + (geo["b_fp_l"] + 0.5 * mf * dfp) * dfp + (geo["b_fp_r"] + 0.5 * mf * dfp) * dfp
+        P_o = (b + 2.0 * hb * np.sqrt(1.0 + m * m)) + (geo["b_fp_l"] + dfp * sf) + (geo["b_fp_r"] + dfp * sf)
+        T_o = (geo["b_fp_l"] + Tb + geo["b_fp_r"]) + 2.0 * mf * dfp
+        A, P, T = np.where(over, A_o, A), np.where(over, P_o, P), np.where(over, T_o, T)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        R = np.where(P > 0.0, A / P, 0.0)
+    dry = d <= 0.0
+    if np.any(dry):
+        A, P, R, T = (np.where(dry, 0.0, v) for v in (A, P, R, T))
+    return A, P, R, T, over
+
+
+def conveyance(geo, hw, pr=None):
+    """Total conveyance; compound sections sum K^1.5 over left / main / right (cross_section.py:741-754)."""
+    A, P, R, T, over = pr if pr is not None else props(geo, hw)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        K = A * np.power(R, 2.0 / 3.0) / geo["n_main"]
+        comp = geo["is_compound"] > 0.5
+        if np.any(comp):
+            z, b, m, hb, mf = geo["z_bed"], geo["b_main"], geo["m_main"], geo["h_bf"], geo["m_fp"]
+            d = np.maximum(0.0, hw - z)
+            dfp = np.where(over, d - hb, 0.0)
+            Tb = b + 2.0 * m * hb
+            sf = np.sqrt(1.0 + mf * mf)
+            A_m = (b + Tb) / 2.0 * hb + Tb * dfp
+            P_m = b + 2.0 * hb * np.sqrt(1.0 + m * m)
+            A_l = (geo["b_fp_l"] + 0.5 * mf * dfp) * dfp; P_l = geo["b_fp_l"] + dfp * sf
+            A_r = (geo["b_fp_r"] + 0.5 * mf * dfp) * dfp; P_r = geo["b_fp_r"] + dfp * sf
+            k = lambda a, n, p: a * np.power(np.where(p > 0, a / np.where(p > 0, p, 1.0), 0.0), 2.0 / 3.0) / n
+            K_m = np.where(over, k(A_m, geo["n_main"], P_m), K)
+            K_l = np.where(over, k(A_l, geo["n_left"], P_l), 0.0)
+            K_r = np.where(over, k(A_r, geo["n_right"], P_r), 0.0)
+            K = np.where(comp, np.power(np.power(K_l, 1.5) + np.power(K_m, 1.5) + np.power(K_r, 1.5), 2.0 / 3.0), K)
+    return K
+
+
+def equivalent_n(geo, hw, pr=None, K=None):
+    """Manning n that reproduces K with the total A and R (cross_section.py:710-739)."""
+    A, P, R, T, over = pr if pr is not None else props(geo, hw)
+    n = np.array(np.broadcast_to(geo["n_main"], np.shape(A)), dtype=np.float64)
+    comp = geo["is_compound"] > 0.5
+    if np.any(comp):
+        K = conveyance(geo, hw, (A, P, R, T, over)) if K is None else K
+        with np.errstate(divide="ignore", invalid="ignore"):
+            neq = A * np.power(R, 2.0 / 3.0) / K
+        n = np.where(comp & (A > 0) & (R > 0) & (K > 0), neq, n)
+    return n
+
+
+def section_table(sections):
+    """list of TrapezoidalSection -> dict of arrays (rows of the FS_GEO_* table)."""
+    f = lambda get: np.array([get(s) for s in sections], dtype=np.float64)
+    return dict(
+        z_bed=f(lambda s: s.z_bed), b_main=f(lambda s: s.b_main), m_main=f(lambda s: s.m_main),
+        n_main=f(lambda s: s.n_main), n_left=f(lambda s: s.n_left), n_right=f(lambda s: s.n_right),
+        is_compound=f(lambda s: 1.0 if s._is_compound else 0.0),
+        h_bf=f(lambda s: s.bankfull_depth if s._is_compound else 0.0),
+        b_fp_l=f(lambda s: s.b_fp_left), b_fp_r=f(lambda s: s.b_fp_right), m_fp=f(lambda s: s.m_fp),
+        curvature=f(lambda s: s.curvature))
+
+
+class CrossSection(ABC):
+    """Common interface (cross_section.py:6-202)."""
+
+    def __init__(self, n=None, bed_slope=None, curvature=0.0):
+        self.n_left = self.n_main = self.n_right = n
+        self.left_fp_limit = self.right_fp_limit = 0.0
+        self.curvature = curvature
+        self.bed_slope = bed_slope
+
+    @property
+    @abstractmethod
+    def z_min(self):
+        ...
+
+    @abstractmethod
+    def properties(self, hw):
+        ...
+
+    def area(self, hw):
+        return self.properties(hw)[0]
+
+    def wetted_perimeter(self, hw):
+        return self.properties(hw)[1]
+
+    def hydraulic_radius(self, hw):
+        return self.properties(hw)[2]
+
+    def top_width(self, hw):
+        return self.properties(hw)[3]
+
+    def dA_dh(self, hw):
+        return self.top_width(hw)
+
+    def get_roughness_para(self):
+        return (self.n_left, self.n_main, self.n_right, self.left_fp_limit, self.right_fp_limit)
+
+    def set_roughness_para(self, parameters):
+        self.n_left, self.n_main, self.n_right, self.left_fp_limit, self.right_fp_limit = parameters
+
+    def friction_slope(self, h, Q):
+        return hydraulics.Sf(Q=Q, K=self.conveyance(hw=h + self.z_min))
+
+    def curvature_slope(self, h, Q):
+        if self.curvature == 0:
+            return 0.0
+        hw = h + self.z_min
+        A, P, R, T = self.properties(hw)
+        return hydraulics.curvature_slope(h=h, T=T, A=A, Q=Q, n=self.get_equivalent_n(hw), R=R, rc=1.0 / self.curvature)
+
+    def normal_flow(self, hw):
+        if self.bed_slope is None or self.bed_slope <= 0.0:
+            return 0.0
+        return hydraulics.normal_flow(bed_slope=self.bed_slope, K=self.conveyance(hw=hw))
+
+    def normal_depth(self, Q_target, hw_max=None):
+        """Depth at which normal_flow == Q_target (cross_section.py:184-202; same bracket, same root finder)."""
+        z = self.z_min
+        hw_max = z + 100 if hw_max is None else hw_max
+        f = lambda hw: Q_target - self.normal_flow(hw=hw)
+        try:
+            return brentq(f, z, hw_max) - z
+        except ValueError:
+            if f(z) < 0:
+                return 0.0
+            if f(hw_max) > 0:
+                return hw_max - z
+            return 0.0
+
+
+class TrapezoidalSection(CrossSection):
+    """Rectangle / simple trapezoid / compound trapezoid with trapezoidal flood plains
+    (cross_section.py:549-613 for the parameters)."""
+
+    def __init__(self, z_bed, b_main, m_main, n_main, z_bank=None, b_fp_left=0.0, b_fp_right=0.0, m_fp=0.0,
+                 n_left=0.03, n_right=0.03, **kwargs):
+        super().__init__(n=n_main, **kwargs)
+        self.z_bed, self.b_main, self.m_main = float(z_bed), float(b_main), float(m_main)
+        self._is_compound = z_bank is not None
+        if self._is_compound:
+            self.z_bank = float(z_bank)
+            if self.z_bank <= self.z_bed:
+                raise ValueError("Bank elevation z_bank must be above bed z_bed")
+            self.b_fp_left, self.b_fp_right, self.m_fp = float(b_fp_left), float(b_fp_right), float(m_fp)
+            self.bankfull_depth = self.z_bank - self.z_bed
+            self.T_main_at_bank = self.b_main + 2.0 * self.m_main * self.bankfull_depth
+            lim = self.T_main_at_bank / 2.0
+        else:
+            self.z_bank = None
+            self.b_fp_left = self.b_fp_right = self.m_fp = 0.0
+            lim = np.inf
+        self._is_rect = (not self._is_compound) and self.m_main == 0.0
+        self._width = np.inf
+        self.set_roughness_para((n_left, n_main, n_right, -lim, lim))
+
+    @property
+    def z_min(self):
+        return self.z_bed
+
+    @property
+    def width(self):
+        return self._width
+
+    def _geo(self):
+        return {k: v[0:1] for k, v in section_table([self]).items()}
+
+    def properties(self, hw):
+        A, P, R, T, _ = props(self._geo(), np.array([float(hw)]))
+        return (float(A[0]), float(P[0]), float(R[0]), float(T[0]))
+
+    def conveyance(self, hw):
+        return float(conveyance(self._geo(), np.array([float(hw)]))[0])
+
+    def get_equivalent_n(self, hw):
+        return float(equivalent_n(self._geo(), np.array([float(hw)]))[0])
+
+    def dR_dA(self, hw):
+        """cross_section.py:766-790."""
+        A, P, R, T = self.properties(hw)
+        if P <= 0.0 or T <= 0.0:
+            return 0.0
+        over = self._is_compound and max(0.0, hw - self.z_bed) > self.bankfull_depth
+        dP_dh = 2.0 * np.sqrt(1.0 + (self.m_fp if over else self.m_main) ** 2)
+        return (P - A * (dP_dh * (1.0 / T))) / (P ** 2)
+
+    def dK_dA(self, hw):
+        """cross_section.py:756-764 (n_eq frozen)."""
+        A, P, R, T = self.properties(hw)
+        if A <= 0.0:
+            return 0.0
+        return (R ** (2 / 3) + A * 2. / 3. * R ** (2 / 3 - 1) * self.dR_dA(hw)) / self.get_equivalent_n(hw)
+
+    def z_at(self, x):
+        """Bed elevation at lateral coordinate x (cross_section.py:795-846)."""
+        x = abs(float(x))
+        half = self.b_main / 2.0
+        if self._is_rect:
+            return self.z_bed if x < half else np.inf
+        if not self._is_compound or x <= self.T_main_at_bank / 2.0:
+            return self.z_bed if x <= half else self.z_bed + (x - half) / self.m_main
+        raise NotImplementedError("flood-plain z_at is only needed for mixed irregular interpolation")
+
+
+def interpolate_cross_section(xs1: CrossSection, xs2: CrossSection, dist1: float, dist2: float) -> CrossSection:
+    """Section at a point between xs1 (dist1 away) and xs2 (dist2 away): every trapezoid
+    parameter, the three roughness values, bed slope and curvature are weighted by the opposite
+    distance (cross_section.py:857-930)."""
+    total = dist1 + dist2
+    if total < 1e-9 or dist1 < 1e-9:
+        return xs1
+    if dist2 < 1e-9:
+        return xs2
+    if not (isinstance(xs1, TrapezoidalSection) and isinstance(xs2, TrapezoidalSection)):
+        raise NotImplementedError("interpolation with IrregularSection is not provided yet (SURVEY.md 8f rank 2)")
+    w1, w2 = dist2 / total, dist1 / total
+    mix = lambda a, b: a * w1 + b * w2
+    y1 = (xs1.z_bank - xs1.z_bed) if xs1._is_compound else 0.0
+    y2 = (xs2.z_bank - xs2.z_bed) if xs2._is_compound else 0.0
+    z_bed = mix(xs1.z_bed, xs2.z_bed)
+    y_bank = mix(y1, y2)
+    slope = None if (xs1.bed_slope is None or xs2.bed_slope is None) else mix(xs1.bed_slope, xs2.bed_slope)
+    return TrapezoidalSection(
+        z_bed=z_bed, b_main=mix(xs1.b_main, xs2.b_main), m_main=mix(xs1.m_main, xs2.m_main),
+        z_bank=(z_bed + y_bank) if y_bank > 1e-6 else None,
+        b_fp_left=mix(xs1.b_fp_left, xs2.b_fp_left), b_fp_right=mix(xs1.b_fp_right, xs2.b_fp_right),
+        m_fp=mix(xs1.m_fp, xs2.m_fp), n_main=mix(xs1.n_main, xs2.n_main), n_left=mix(xs1.n_left, xs2.n_left),
+        n_right=mix(xs1.n_right, xs2.n_right), bed_slope=slope, curvature=mix(xs1.curvature, xs2.curvature))

@@ -1,0 +1,106 @@
+"""PreissmannSolver: the reference's entry point for the implicit 4-point scheme
+(src/hydromodel/preissmann.py:9-163) with run() executed on an MI355X.
+
+run() flattens the channel (node geometry table, two boundary specs, initial conditions) into a
+one-reach PreissmannBatch, advances all time levels in one kernel launch and copies the
+depth/flow[nt, N] history back.  Error behaviour follows the reference: ValueError when a level
+does not converge within max_iter (preissmann.py:124-126) or the residual turns NaN (:135-137).
+"""
+import numpy as np
+
+from .. import _abi as A
+from ..batch import BoundarySpec, PreissmannBatch
+from .hydraulics import froude_array
+from .solver import Solver
+from . import cross_section as XS
+
+_KIND = {"flow": A.BC_FLOW_HYDROGRAPH, "stage": A.BC_STAGE_HYDROGRAPH, "fixed": A.BC_FIXED_DEPTH,
+         "normal": A.BC_NORMAL_DEPTH, "power": A.BC_RATING_POWER, "poly": A.BC_RATING_POLY,
+         "blend": A.BC_RATING_BLEND, "storage": A.BC_STORAGE}
+
+
+def boundary_to_spec(boundary, n_levels, dt) -> BoundarySpec:
+    kind, params, target = boundary.device_spec(n_levels, dt)
+    return BoundarySpec(_KIND[kind], params, target)
+
+
+class PreissmannSolver(Solver):
+    def __init__(self, theta, **kwargs):
+        super().__init__(**kwargs)
+        self.theta = theta
+        self.unknowns = None
+        self.type = 'preissmann'
+        self.iterations = None                     # Newton iterations per time level, filled by run()
+        self.initialize_t0()
+
+    def initialize_t0(self) -> None:
+        super().initialize_t0()
+        self.unknowns = self.channel.initial_conditions.flatten()     # x = [h0, Q0, h1, Q1, ...]
+
+    def run(self, tolerance=1e-4, verbose=3, max_iter=100, diagnos=False, dtype="f64") -> None:
+        ch = self.channel
+        N, nt = self.number_of_nodes, self.number_of_time_levels
+        geo = ch.node_geometry
+        rect = (np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)
+                and np.ptp(geo["b_main"]) == 0 and np.ptp(geo["n_main"]) == 0 and ch.input_xs is not None
+                and len(ch.input_xs) == 2)
+        with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode="rect_uniform" if rect else "table",
+                             history=True) as b:
+            b.set_scheme(self.theta, self.time_step, self.spatial_step, tolerance, max_iter)
+            if rect:
+                b.set_geometry_uniform(geo["b_main"][0], geo["n_main"][0], geo["z_bed"][0], geo["z_bed"][-1])
+            else:
+                b.set_geometry_table(geo)
+            b.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step))
+            b.set_boundary(A.DOWNSTREAM, boundary_to_spec(ch.downstream_boundary, max(nt, 2), self.time_step))
+            b.set_state(ch.initial_conditions[:, 0], ch.initial_conditions[:, 1])
+            if nt > 1:
+                b.step(nt - 1)
+            status = int(b.status()[0])
+            its = b.iterations(0, max(nt, 2))[:nt, 0]
+            h, Q = b.history_arrays(0, max(nt, 2))
+            gh, gQ = b.guess()
+            stages = b.storage_stages(0, max(nt, 2))[:nt, 0] if ch.downstream_boundary.lumped_storage is not None else None
+        self.iterations = its
+        self.unknowns = np.empty(2 * N)
+        self.unknowns[0::2], self.unknowns[1::2] = gh[0], gQ[0]
+        if status != A.OK:
+            # levels before the failing one are complete; the failing level keeps the last Newton vector
+            k_fail = int(np.flatnonzero(its > 0)[-1]) if np.any(its > 0) else 1
+            self.time_level = k_fail
+            self.depth[:k_fail], self.flow[:k_fail] = h[:k_fail, 0], Q[:k_fail, 0]
+            self.depth[k_fail], self.flow[k_fail] = gh[0], gQ[0]
+            self.check_criticality()
+            if status == A.MAX_ITER:
+                raise ValueError(f'Convergence within {max_iter} iterations couldn\'t be achieved.')
+            if status == A.STORAGE_RANGE:
+                raise ValueError("f(a) and f(b) must have different signs")      # what brentq raises in the reference
+            raise ValueError("NaN in system assembly")
+        self.time_level = nt - 1
+        self.depth[:], self.flow[:] = h[:nt, 0], Q[:nt, 0]
+        st = ch.downstream_boundary.lumped_storage
+        if st is not None:
+            st.stage_hydrograph = [[k * self.time_step, float(stages[k])] for k in range(1, nt)]
+        if verbose >= 1:
+            for k in range(1, nt):
+                print(f'\n> Time level #{k}')
+                if verbose >= 2:
+                    print(f'>> {its[k]} iterations.')
+        self._finalize(verbose)
+
+    def check_criticality(self) -> None:
+        """Froude diagnosis printed before a convergence failure is raised (preissmann.py:179-198)."""
+        geo = self.channel.node_geometry
+        k = self.time_level
+        A_, P, R, T, _ = XS.props(geo, self.depth[k] + geo["z_bed"])
+        fr = froude_array(T, A_, self.flow[k])
+        bad = False
+        for x, f in zip(self.channel.ch_at_node, fr):
+            if f == 1.0:
+                bad = True
+                print(f'WARNING: Flow goes critical at x = {x} m. Fr = {f}.')
+            elif f > 1.0:
+                bad = True
+                print(f'WARNING: Flow goes supercritical at x = {x} m. Fr = {f}.')
+        if not bad:
+            print('Flow is subcritical.')

@@ -141,6 +141,9 @@ int fs_batch_get_status(fs_batch *b, int32_t *out);                             
 int fs_batch_get_history(fs_batch *b, int32_t first_level, int32_t n_levels, double *h, double *Q);
 /* reservoir stage kept per level by the storage boundary (boundary.py:126-131): out[B] */
 int fs_batch_get_storage_stage(fs_batch *b, double *out);
+/* the same per time level (LumpedStorage.stage_hydrograph, boundary.py:126-131): out[n_levels][B],
+ * rows of levels that have not been computed (and level 0) are 0 */
+int fs_batch_get_storage_stages(fs_batch *b, int32_t first_level, int32_t n_levels, double *out);
 
 /* zero-copy access for device-side consumers (RCCL gather of hydrographs): device pointer to the
  * [max_levels][4][B] hydrograph block in the batch dtype, and the handle's hipStream_t */

@@ -1,0 +1,96 @@
+"""The golden cases rebuilt through the host mirror (flowsim_amd.hydromodel) with the same calls
+oracle/gen_golden.py made against the reference: used to check the mirror's geometry / initial
+conditions on the CPU and the whole drop-in path (Channel -> PreissmannSolver.run) on the GPU."""
+from math import cos, pi, sin
+
+import numpy as np
+
+from flowsim_amd.hydromodel import (Boundary, Channel, Hydrograph, LumpedStorage, PreissmannSolver, RatingCurve,
+                                    TrapezoidalSection)
+
+
+def akbari_shape(Q_b, Q_p, t_p, t_b):
+    def f(t):
+        if t <= t_p:
+            return Q_p / 2 * sin(pi * t / t_p - pi / 2) + Q_p / 2 + Q_b
+        elif t <= t_b:
+            return Q_p / 2 * cos(pi * (t - t_p) / (t_b - t_p)) + Q_p / 2 + Q_b
+        return Q_b
+    return f
+
+
+def akbari():
+    from cases.akbari_firoozi.main_preissmann import build
+    from cases.akbari_firoozi import settings as S
+    return build(), S.tolerance
+
+
+def example():
+    from cases.example.main import build
+    return build(), 1e-4
+
+
+def bc_stage_fixed():
+    L = 12000.0
+    tab = np.array([[0, 8.0 + 3.0], [3600 * 2, 8.0 + 3.6], [3600 * 5, 8.0 + 3.1], [3600 * 12, 8.0 + 3.0]])
+    us = Boundary(condition='stage_hydrograph', bed_level=8.0, chainage=0, initial_depth=3.0, hydrograph=Hydrograph(table=tab))
+    ds = Boundary(condition='fixed_depth', bed_level=0.0, chainage=L, initial_depth=4.0)
+    ch = Channel(width=80, initial_flow=300.0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds,
+                 interpolation_method='linear')
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=900, spatial_step=500, simulation_time=8 * 3600), 1e-6
+
+
+def bc_trap_poly():
+    L = 15000.0; S0 = 4e-4
+    xs_u = TrapezoidalSection(z_bed=100.0 + S0 * L, b_main=40.0, m_main=1.5, n_main=0.032, bed_slope=S0)
+    xs_m = TrapezoidalSection(z_bed=100.0 + S0 * L * 0.4, b_main=55.0, m_main=2.0, n_main=0.028, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=100.0, b_main=60.0, m_main=2.5, n_main=0.03, bed_slope=S0)
+    rc = RatingCurve(); rc.set(type='polynomial', a=9.0, b=35.0, c=-20.0)
+    rc.stage_shift = -100.0
+    h_ds = 3.0
+    Q0 = rc.discharge(100.0 + h_ds)
+    hyd = Hydrograph(akbari_shape(Q0, 1.5 * Q0, 3 * 3600.0, 9 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=xs_u.z_bed, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='rating_curve', bed_level=100.0, chainage=L, initial_depth=h_ds, rating_curve=rc)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds)
+    ch.set_cross_sections([0.0, 0.6 * L, L], [xs_u, xs_m, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.6, time_step=1200, spatial_step=600, simulation_time=10 * 3600), 1e-6
+
+
+def bc_compound_normal():
+    L = 20000.0; S0 = 3e-4
+
+    def comp(z, b, m, hb, bl, br, mf, slope):
+        return TrapezoidalSection(z_bed=z, b_main=b, m_main=m, n_main=0.03, z_bank=z + hb, b_fp_left=bl,
+                                  b_fp_right=br, m_fp=mf, n_left=0.06, n_right=0.05, bed_slope=slope)
+    xs_u = comp(S0 * L, 30.0, 2.0, 2.5, 60.0, 40.0, 4.0, S0)
+    xs_d = comp(0.0, 36.0, 1.5, 2.2, 80.0, 50.0, 3.0, S0)
+    hyd = Hydrograph(akbari_shape(120.0, 500.0, 2 * 3600.0, 7 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L)
+    ch = Channel(initial_flow=120.0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.65, time_step=600, spatial_step=500, simulation_time=6 * 3600), 1e-6
+
+
+def synthetic_trap(member, N=64, n_steps=5, seed=20260214, theta=0.6, dt=1800, dx=500.0, tol=1e-6):
+    """SURVEY 8d C5 generator in fp64 (simple trapezoid + power rating curve), member-th draw."""
+    rng = np.random.default_rng(seed)
+    for _ in range(member + 1):
+        b = rng.uniform(20, 100); m = rng.uniform(1, 3); n = rng.uniform(0.025, 0.04)
+        S0 = rng.uniform(2e-4, 1e-3); Qb = rng.uniform(50, 500) * (b / 100)
+    L = (N - 1) * dx
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=b, m_main=m, n_main=n, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=0.0, b_main=b, m_main=m, n_main=n, bed_slope=S0)
+    h_n = xs_d.normal_depth(Q_target=Qb)
+    rc = RatingCurve(); rc.set(type='power', a=Qb / h_n ** 1.6, b=1.6)
+    hyd = Hydrograph(akbari_shape(Qb, 2 * Qb, 5 * 3600.0, 15 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_n, rating_curve=rc)
+    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx, simulation_time=n_steps * dt), tol
+
+
+BUILDERS = {"akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
+            "bc_compound_normal": bc_compound_normal}

@@ -1,0 +1,60 @@
+"""The whole drop-in path on the GPU: case scripts written against the reference's API
+(Channel / Boundary / ... / PreissmannSolver.run) reproduce the reference's depth/flow history.
+Tolerance 1e-8 relative (north_star), identical Newton iteration counts."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import preissmann_oracle as O
+import case_builders as CB
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def rel(got, want, floor):
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor)))
+
+
+@pytest.mark.parametrize("name", sorted(CB.BUILDERS))
+def test_case_through_reference_api(name):
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, tol = CB.BUILDERS[name]()
+    solver.run(tolerance=tol, verbose=0)
+    assert solver.depth.shape == (meta["nt"], meta["N"])
+    assert rel(solver.depth, fx["depth"], 1e-3) <= TOL
+    assert rel(solver.flow, fx["flow"], 1.0) <= TOL
+    assert np.array_equal(solver.iterations, fx["iters"])
+    assert rel(solver.unknowns, fx["final_unknowns"], 1e-3) <= 1e-7     # Newton vector seeding the next level
+    # derived fields of prepare_results exist and are consistent
+    assert solver.level.shape == solver.depth.shape and np.all(solver.area > 0)
+    np.testing.assert_allclose(solver.velocity * solver.area, solver.flow, rtol=1e-12)
+
+
+def test_example_storage_stage_hydrograph():
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "example.npz"))
+    solver, tol = CB.example()
+    solver.run(tolerance=tol, verbose=0)
+    st = solver.channel.downstream_boundary.lumped_storage
+    got = np.array(st.stage_hydrograph)[1:, 1]                 # [0] is the level-0 entry prepare_results inserts
+    assert rel(got, fx["storage_stage"][:, 1], 1e-3) <= TOL
+    assert abs(solver.flow[1, -1] - (-999.9613412523)) < 1e-6   # the reference's negative first outflow
+
+
+def test_synthetic_trapezoid_power_rating():
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "synthetic_trap_64.npz"))
+    for mem in range(meta["B"]):
+        solver, tol = CB.synthetic_trap(mem)
+        solver.run(tolerance=tol, verbose=0)
+        assert rel(solver.depth, fx["depth"][mem], 1e-3) <= TOL
+        assert rel(solver.flow, fx["flow"][mem], 1.0) <= TOL
+        assert np.array_equal(solver.iterations, fx["iters"][mem])
+
+
+def test_non_convergence_raises_like_the_reference(capsys):
+    solver, tol = CB.akbari()
+    with pytest.raises(ValueError, match="Convergence within 1 iterations couldn't be achieved."):
+        solver.run(tolerance=1e-12, verbose=0, max_iter=1)
+    assert "subcritical" in capsys.readouterr().out              # check_criticality ran first

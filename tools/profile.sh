@@ -1,0 +1,15 @@
+#!/bin/bash
+# rocprofv3 runs for profiles/: kernel trace + stats, then HBM traffic counters in separate passes
+# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; never combine --pmc with sys traces)
+set -e
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--reaches 65536 --steps 8 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || true
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || true
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err || true
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err || true
+find $OUT -name "*.csv" | head -50
+du -sh $OUT
