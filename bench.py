@@ -30,44 +30,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flow-sim_amd"))
 sys.path.insert(0, ROOT)
 
-SEED = 20260213
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, the unit this kernel actually runs on
 
 
-def c3_reach_parameters(first, count):
-    """SURVEY 8d C3 draws for global reach indices [first, first+count): b, n, S0, Q_base."""
-    rng = np.random.default_rng(SEED)
-    u = rng.random((first + count, 4))[first:]           # same stream as 4 scalar draws per reach
-    b = 50.0 + 250.0 * u[:, 0]
-    n = 0.02 + 0.02 * u[:, 1]
-    S0 = 2e-4 + 8e-4 * u[:, 2]
-    Qb = (50.0 + 450.0 * u[:, 3]) * (b / 100.0)
-    return b, n, S0, Qb
-
-
-def normal_depth_rect(b, n, S0, Q):
-    """Vectorised bisection for Q = K(h) sqrt(S0) in a rectangle (host-side IC, channel.py:296-305)."""
-    lo = np.full_like(b, 1e-9)
-    hi = np.full_like(b, 200.0)
-    for _ in range(200):
-        mid = 0.5 * (lo + hi)
-        A = b * mid
-        P = b + 2 * mid
-        below = A * (A / P) ** (2.0 / 3.0) / n * np.sqrt(S0) < Q
-        lo = np.where(below, mid, lo)
-        hi = np.where(below, hi, mid)
-    return 0.5 * (lo + hi)
-
-
-def inflow_table(Qb, levels, dt):
-    """akbari-shaped hydrograph (cases/akbari_firoozi/settings.py:22-34 form) with Q_p = 2 Q_base."""
-    t = np.arange(levels)[:, None] * dt
-    tp, tb = 5 * 3600.0, 15 * 3600.0
-    Qp = 2.0 * Qb[None, :]
-    rise = Qp / 2 * np.sin(np.pi * t / tp - np.pi / 2) + Qp / 2 + Qb[None, :]
-    fall = Qp / 2 * np.cos(np.pi * (t - tp) / (tb - tp)) + Qp / 2 + Qb[None, :]
-    return np.where(t <= tp, rise, np.where(t <= tb, fall, Qb[None, :]))
+from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect  # noqa: E402
+from flowsim_amd.shard import gather_hydrographs, reach_block  # noqa: E402
 
 
 def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
@@ -134,7 +102,8 @@ def main():
     B, N, K, Wm = args.reaches, args.nodes, args.steps, args.warmup
     theta, dt, dx, tol = 0.6, 600.0, 250.0, 1e-6
     levels = K + Wm + 1
-    b_, n_, S0, Qb = c3_reach_parameters(rank * B, B)
+    first, _ = reach_block(rank, world, B)
+    b_, n_, S0, Qb = c3_reach_parameters(first, B)
     hn = normal_depth_rect(b_, n_, S0, Qb)
     L = (N - 1) * dx
 
@@ -156,7 +125,6 @@ def main():
     v.__cuda_array_interface__ = {"shape": (levels, 4, B), "typestr": "<f8" if esz == 8 else "<f4",
                                   "data": (batch.hydrograph_device_ptr(), False), "version": 2}
     hyd_dev = torch.as_tensor(v, device=f"cuda:{local}")
-    gathered = torch.empty((world, K, 4, B), dtype=tdt, device=f"cuda:{local}") if world > 1 else None
 
     def barrier():
         if world > 1:
@@ -170,8 +138,8 @@ def main():
     t0 = time.perf_counter()
     batch.step(K, sync=False)
     batch.sync()
-    if world > 1:      # the only exchange of the path: boundary hydrographs of the timed levels
-        dist.all_gather_into_tensor(gathered.view(world * K, 4, B), hyd_dev[Wm + 1:Wm + 1 + K].contiguous())
+    # the only exchange of the path: boundary hydrographs of the timed levels, [K, 4, world*B] on every rank
+    gathered = gather_hydrographs(hyd_dev[Wm + 1:Wm + 1 + K], world)
     barrier()
     el = time.perf_counter() - t0
     kern_ms = batch.last_step_ms()

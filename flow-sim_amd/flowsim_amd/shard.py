@@ -1,0 +1,31 @@
+"""Reach sharding across the GPUs of a node and the one collective of the path.
+
+Reaches / ensemble members are independent: each rank owns a contiguous
+block of global reach indices and steps it without talking to anyone.  The only exchange is the
+gather of the boundary hydrographs [levels, 4, B_local] - an all_gather over RCCL (backend
+"nccl" on ROCm) or gloo (CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def reach_block(rank: int, world: int, per_rank: int):
+    """Weak-scaling layout used by bench.py: rank r owns [r*per_rank, (r+1)*per_rank)."""
+    return rank * per_rank, per_rank
+
+
+def split_reaches(total: int, rank: int, world: int):
+    """Strong-scaling layout: `total` reaches in `world` contiguous blocks, remainder to the first ranks."""
+    base, rem = divmod(total, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def gather_hydrographs(local: torch.Tensor, world: int) -> torch.Tensor:
+    """local [levels, 4, B] on every rank -> [levels, 4, world*B] in global reach order (all ranks)."""
+    if world == 1:
+        return local
+    local = local.contiguous()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local)
+    return out.permute(1, 2, 0, 3).reshape(local.shape[0], local.shape[1], world * local.shape[2])
