@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: all ranks use cuda:0 (multi-rank control flow on a one-GPU box, gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,10 +97,15 @@ def main():
     from flowsim_amd import BoundarySpec, PreissmannBatch
     from flowsim_amd import _abi as A
 
+    if args.share_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
 
     B, N, K, Wm = args.reaches, args.nodes, args.steps, args.warmup
     theta, dt, dx, tol = 0.6, 600.0, 250.0, 1e-6
@@ -139,7 +147,9 @@ def main():
     batch.step(K, sync=False)
     batch.sync()
     # the only exchange of the path: boundary hydrographs of the timed levels, [K, 4, world*B] on every rank
-    gathered = gather_hydrographs(hyd_dev[Wm + 1:Wm + 1 + K], world)
+    timed_rows = hyd_dev[Wm + 1:Wm + 1 + K]
+    gathered = gather_hydrographs(timed_rows if args.backend == "nccl" or world == 1 else timed_rows.cpu(), world)
+    assert gathered.shape == (K, 4, world * B)
     barrier()
     el = time.perf_counter() - t0
     kern_ms = batch.last_step_ms()
@@ -151,6 +161,8 @@ def main():
     kms_t = torch.tensor([kern_ms], dtype=torch.float64, device=f"cuda:{local}")
     it_t = torch.tensor([float(its.sum()), float(ok)], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
+        if args.backend != "nccl":
+            el_t, kms_t, it_t = el_t.cpu(), kms_t.cpu(), it_t.cpu()
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(kms_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
