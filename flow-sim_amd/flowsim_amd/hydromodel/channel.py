@@ -118,7 +118,7 @@ class Channel:
                 kappa = 0.0
             else:
                 ang = np.arccos(np.clip(np.dot(v1, v2) / (l1 * l2), -1.0, 1.0))
-                kappa = 2 * np.sin(ang / 2) / (0.5 * (l1 + l2)) * np.sign(np.cross(v1, v2))
+                kappa = 2 * np.sin(ang / 2) / (0.5 * (l1 + l2)) * np.sign(v1[0] * v2[1] - v1[1] * v2[0])
             self.input_xs[i].curvature = kappa
 
     # ---- initial conditions ------------------------------------------------------------------------

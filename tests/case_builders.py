@@ -92,5 +92,21 @@ def synthetic_trap(member, N=64, n_steps=5, seed=20260214, theta=0.6, dt=1800, d
     return PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx, simulation_time=n_steps * dt), tol
 
 
-BUILDERS = {"akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
+def gerd():
+    """cases/gerd_roseires, first 48 h of the regulated scenario with the tabulated inflow (tests/golden/gerd.npz)."""
+    from cases.gerd_roseires.model import build
+    from cases.gerd_roseires import settings as S
+    solver, _ = build(inflow_hyd_func=None, sim_duration=48 * 3600)
+    return solver, S.tolerance
+
+
+def gerd_member(n_main):
+    """one member of the Manning-n study (n_calibrate set-up: short inflow table, no curvature)."""
+    from cases.gerd_roseires.n_calibrate import member_setup
+    from cases.gerd_roseires import settings as S
+    solver, _ = member_setup(n_main)
+    return solver, S.tolerance
+
+
+BUILDERS = {"gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
             "bc_compound_normal": bc_compound_normal}

@@ -58,3 +58,24 @@ def test_non_convergence_raises_like_the_reference(capsys):
     with pytest.raises(ValueError, match="Convergence within 1 iterations couldn't be achieved."):
         solver.run(tolerance=1e-12, verbose=0, max_iter=1)
     assert "subcritical" in capsys.readouterr().out              # check_criticality ran first
+
+
+def test_manning_ensemble_batch_matches_sequential_reference_runs():
+    """BASELINE configs[3] semantics at small size: 8 members of the gerd_roseires n-study in one
+    device batch == 8 separate runs of the reference (tests/golden/gerd_ensemble.npz)."""
+    from cases.gerd_roseires.n_calibrate import member_setup
+    from flowsim_amd.ensemble import run_manning_ensemble
+    from cases.gerd_roseires import settings as S
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "gerd_ensemble.npz"))
+    ns = fx["n_members"]
+    solvers = [member_setup(float(n))[0] for n in ns]
+    lead = solvers[0]
+    lead.channel.member_ics = np.stack([s.channel.initial_conditions for s in solvers])
+    res = run_manning_ensemble(lead, ns, tolerance=S.tolerance)
+    assert np.all(res["status"] == 0)
+    for i in range(len(ns)):
+        hy = res["hydrographs"][:, :, i]
+        for col, (arr, node, floor) in enumerate(((fx["depth"], 0, 1e-3), (fx["flow"], 0, 1.0),
+                                                  (fx["depth"], -1, 1e-3), (fx["flow"], -1, 1.0))):
+            assert rel(hy[:, col], arr[i][:, node], floor) <= TOL, (i, col)
+        assert np.array_equal(res["iterations"][:, i], fx["iters"][i])

@@ -77,3 +77,29 @@ def test_src_import_paths():
     from src.hydromodel.preissmann import PreissmannSolver            # noqa: F401
     from src.hydromodel.rating_curve import RatingCurve               # noqa: F401
     from src.hydromodel.lax import LaxSolver                          # noqa: F401
+
+
+def test_gerd_ensemble_member_setup():
+    """Manning-n override is applied before interpolation; every member starts from its own GVF profile."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "gerd_ensemble.npz"))
+    for mem in (0, 3, 7):
+        solver, tol = CB.gerd_member(float(fx["n_members"][mem]))
+        assert solver.number_of_nodes == meta["N"] and solver.number_of_time_levels == meta["nt"]
+        np.testing.assert_allclose(solver.channel.node_geometry["n_main"], fx["geo_n_main"][mem], rtol=1e-14)
+        np.testing.assert_allclose(solver.channel.initial_conditions, fx["initial_conditions"][mem], rtol=1e-11)
+        np.testing.assert_allclose(solver.channel.upstream_boundary.hydrograph.sample(meta["nt"], 3600),
+                                   fx["us_target"][mem], rtol=1e-13)
+
+
+def test_roseires_rating_curve_matches_reference_samples():
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "gerd.npz"))
+    solver, _ = CB.gerd()
+    rc = solver.channel.downstream_boundary.rating_curve
+    assert rc.closed_state[1] == meta["rating"]["closed_state"][1]
+    np.testing.assert_allclose(rc.closed_state[0], meta["rating"]["closed_state"][0])
+    q = np.array([rc.discharge(s) for s in fx["rating_probe_stage"]])
+    np.testing.assert_allclose(q, fx["rating_probe_Q"], rtol=1e-12)
+    kind, p = rc.device_spec(solver.channel.downstream_boundary.bed_level)
+    assert kind == "blend"
+    np.testing.assert_allclose([p["lo0"], p["lo1"], p["lo2"]], meta["rating"]["low"], rtol=1e-12)
+    np.testing.assert_allclose([p["hi0"], p["hi1"], p["hi2"]], meta["rating"]["high"], rtol=1e-12)
