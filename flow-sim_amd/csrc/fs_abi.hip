@@ -54,7 +54,8 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),   \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),                                          \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true),                                           \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
@@ -112,6 +113,7 @@ struct fs_batch {
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
   void *Yprev = nullptr, *stage_hist = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
   int32_t *iters = nullptr, *status = nullptr;
+  unsigned long long *dbg = nullptr;
 };
 
 namespace {
@@ -168,6 +170,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   }
   a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
+  a.dbg = b->dbg;
 }
 
 }  // namespace
@@ -229,6 +232,10 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
     if ((e = hipMalloc(&b->hist_Q, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
   }
+#ifdef FS_STAMP
+  if ((e = hipMalloc((void **)&b->dbg, B * 16 * 8 * 8)) != hipSuccess) return bad("hipMalloc(dbg)", e);
+  hipMemsetAsync(b->dbg, 0, B * 16 * 8 * 8, b->stream);
+#endif
   hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
   hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);
   hipMemsetAsync(b->status, 0, B * 4, b->stream);
@@ -455,6 +462,16 @@ double fs_batch_last_step_ms(fs_batch *b) {
 }
 
 int32_t fs_batch_last_launch_count(fs_batch *b) { return b ? b->launches : 0; }
+
+#ifdef FS_STAMP
+// diagnostic builds only: out[B][16][8] cycle sums (waves beyond W are zero)
+int fs_debug_stamps(fs_batch *b, unsigned long long *out) {
+  if (!b || !out || !b->dbg) return fail("fs_debug_stamps: not available");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  HIP_TRY(hipMemcpy(out, b->dbg, (size_t)b->d.n_reaches * 16 * 8 * 8, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 
 int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach, int32_t *lds_bytes,
                          int32_t *vgprs) {

@@ -37,6 +37,19 @@
 
 namespace fs {
 
+// In-kernel phase stamps for diagnostic builds only (never in the shipped library): cycle sums per
+// phase of the Newton iteration, one row per wave, written once at the end of the launch.
+#ifdef FS_STAMP
+#define FS_T(i)                                                         \
+  do {                                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+    stamp_[i] += now_ - tprev_;                                         \
+    tprev_ = now_;                                                      \
+  } while (0)
+#else
+#define FS_T(i) do { } while (0)
+#endif
+
 template <typename R> struct KernelArgs {
   int32_t B, N, n_steps, level0, max_iter;
   R theta, dt, dx, tol;
@@ -52,6 +65,7 @@ template <typename R> struct KernelArgs {
   int32_t *iters;          // [levels][B]
   int32_t *status;         // [B]
   R *hist_h, *hist_Q;      // [levels][B][N] or nullptr
+  unsigned long long *dbg; // diagnostic builds (-DFS_STAMP): [B][W][8] cycle sums per phase, else nullptr
 };
 
 template <typename R, int SEC> struct Geometry;
@@ -206,21 +220,25 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
   __syncthreads();
 
+  {   // accepted state of the entry level -> 4 constants per cell in LDS (later levels: from registers, below)
+    R hk[M + 1], Qk[M + 1];
+#pragma unroll
+    for (int j = 0; j <= M; ++j) {
+      const int node = min(s0 + j, N - 1);
+      hk[j] = a.hk[base + node]; Qk[j] = a.Qk[base + node];
+    }
+    if (t == tD) {
+#pragma unroll
+      for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Qk[j];
+    }
+    write_level_constants(hk, Qk);
+  }
+#ifdef FS_STAMP
+  unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
     const int level = a.level0 + step + 1;
-    {   // accepted state of level k -> 4 constants per cell in LDS (own stores of the previous level are visible)
-      R hk[M + 1], Qk[M + 1];
-#pragma unroll
-      for (int j = 0; j <= M; ++j) {
-        const int node = min(s0 + j, N - 1);
-        hk[j] = a.hk[base + node]; Qk[j] = a.Qk[base + node];
-      }
-      if (t == tD) {
-#pragma unroll
-        for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Qk[j];
-      }
-      write_level_constants(hk, Qk);
-    }
     int it = 0;
     bool converged = false;
     R Ynew = Yprev;
@@ -228,6 +246,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       ++it;
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
       parity ^= 1;
+      FS_T(7);
 
       // opaque lane offset (an integer, so the accesses stay LDS ds_read, not flat): the 4*M level
       // constants are Newton-loop invariants and would otherwise be hoisted into registers
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       }
 
 #endif
+      FS_T(0);
       // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
@@ -385,6 +405,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         if (flag) sm.xflag[parity] = flag;
       }
 
+      FS_T(1);
       // ================= 3. in-wave tree (up-sweep) =================
 #pragma unroll
       for (int l = 0; l < 6; ++l) {
@@ -407,7 +428,9 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         p[5] = seg.pm0; p[6] = seg.pm1; p[7] = seg.sm0; p[8] = seg.sm1; p[9] = seg.qm;
         sm.xnorm[parity][wave] = nrm2;
       }
+      FS_T(2);
       __syncthreads();
+      FS_T(3);
 
       // ================= 4. across waves: fold, close with the boundary rows, unfold =================
       R tot = R(0);
@@ -438,42 +461,13 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         for (int w = 1; w < W; ++w)
           if (wave == w) { bL0 = bnd[w][0]; bL1 = bnd[w][1]; bR0 = bnd[w + 1][0]; bR1 = bnd[w + 1][1]; }
       }
+      FS_T(4);
       const R err = sqrt_(tot);                                        // utility.py:20-22
       if (sm.xflag[parity] != 0) status = sm.xflag[parity];
       if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
       converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
 
-      // ================= 5. accepted iterate -> level k (SURVEY F2) =================
-      if (converged) {
-        if (t == 0) {
-          a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
-          a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
-          a.iters[(size_t)level * a.B + reach] = it;
-        }
-        {
-          R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
-          R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
-#pragma unroll
-          for (int j = 0; j <= M; ++j) {
-            const int node = s0 + j;
-            if ((j < M || node == N - 1) && node < N) {
-              hk_p[j] = h[j]; Qk_p[j] = Q[j];
-              if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
-            }
-          }
-        }
-        if (t == tD) {
-#pragma unroll
-          for (int j = 1; j <= M; ++j)
-            if (j == jD) {
-              a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
-              a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
-            }
-          Yprev = Ynew;
-          if (a.ds.kind == FS_BC_STORAGE) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
-        }
-      }
-
+      FS_T(5);
       // ================= 6. separators down the tree, local back-substitution, update ============
       R dR0 = bR0, dR1 = bR1;       // valid on lane 63; filled for every lane below
 #pragma unroll
@@ -496,7 +490,10 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       R dL0 = shfl_up_(dR0, 1), dL1 = shfl_up_(dR1, 1);
       if (lane == 0) { dL0 = bL0; dL1 = bL1; }
 
-      R n0 = dR0, n1 = dR1;         // update of node j+1, applied once its old value is no longer needed
+      // The update is kept pending in dh/dQ (they take the registers the elimination records free up):
+      // the accepted iterate must still be intact for the level-constant pass below.
+      R dh[M + 1], dQ[M + 1];
+      dh[M] = dR0; dQ[M] = dR1; dh[0] = dL0; dQ[0] = dL1;
       if (Geo::kConstT && FS_LAUNDER_BACK) {
         // The continuity residuals are recomputed below on purpose (one value per node less to keep
         // across the solve).  Hide the operands so that common-subexpression elimination does not
@@ -506,28 +503,71 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
 #pragma unroll
         for (int j = 0; j <= M; ++j) asm volatile("" : "+v"(h[j]), "+v"(Q[j]));
       }
+      {
+        R n0 = dR0, n1 = dR1;
 #pragma unroll
-      for (int j = M - 1; j >= 1; --j) {
-        const LocalElim<R> &e = el[j - 1];
-        // pivot block rows: (sm0, sm1) and the continuity row of cell j: (T_j/(2dt), -cq | T_{j+1}/(2dt), cq)
-        const bool real = (RAGGED || j == M - 1) ? (s0 + j < NC) : true;   // else identity padding
-        R c0, b0, qc;
-        if (Geo::kConstT) {
-          c0 = geo.terms_T() * r2dt; b0 = c0;
-          qc = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
-        } else {
-          c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc.get();
+        for (int j = M - 1; j >= 1; --j) {
+          const LocalElim<R> &e = el[j - 1];
+          // pivot block rows: (sm0, sm1) and the continuity row of cell j: (T_j/(2dt), -cq | T_{j+1}/(2dt), cq)
+          const bool real = (RAGGED || j == M - 1) ? (s0 + j < NC) : true;   // else identity padding
+          R c0, b0, qc;
+          if (Geo::kConstT) {
+            c0 = geo.terms_T() * r2dt; b0 = c0;
+            qc = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
+          } else {
+            c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc.get();
+          }
+          const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
+          if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
+          const R rsig = e.rq.get() - (e.rp0.get() * dL0 + e.rp1.get() * dL1);
+          const R tau = qc - (b0 * n0 + b1 * n1);
+          n0 = c1 * rsig - e.rs1.get() * tau;
+          n1 = e.rs0.get() * tau - c0 * rsig;
+          dh[j] = n0; dQ[j] = n1;
         }
-        h[j + 1] += n0; Q[j + 1] += n1;
-        const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
-        if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
-        const R rsig = e.rq.get() - (e.rp0.get() * dL0 + e.rp1.get() * dL1);
-        const R tau = qc - (b0 * n0 + b1 * n1);
-        n0 = c1 * rsig - e.rs1.get() * tau;
-        n1 = e.rs0.get() * tau - c0 * rsig;
       }
-      h[1] += n0; Q[1] += n1;
-      h[0] += dL0; Q[0] += dL1;                                        // preissmann.py:146-147
+      FS_T(6);
+
+      // ================= 5. accepted iterate -> level k (SURVEY F2) =================
+      if (converged) {
+        if (t == 0) {
+          a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
+          a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
+          a.iters[(size_t)level * a.B + reach] = it;
+        }
+        {
+          // (a transposed, fully coalesced write-back through LDS was measured: no gain, three extra barriers)
+          R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+#pragma unroll
+          for (int j = 0; j <= M; ++j) {
+            const int node = s0 + j;
+            if ((j < M || node == N - 1) && node < N) {
+              hk_p[j] = h[j]; Qk_p[j] = Q[j];
+              if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
+            }
+          }
+        }
+        if (t == tD) {
+#pragma unroll
+          for (int j = 1; j <= M; ++j)
+            if (j == jD) {
+              a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
+              a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
+            }
+          Yprev = Ynew;
+          if (a.ds.kind == FS_BC_STORAGE) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
+        }
+        if (t == tD) {
+#pragma unroll
+          for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
+        }
+        write_level_constants(h, Q);                                  // level constants of the next level
+      }
+
+      FS_T(5);
+#pragma unroll
+      for (int j = 0; j <= M; ++j) { h[j] += dh[j]; Q[j] += dQ[j]; }     // preissmann.py:146-147
     }
     if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
   }
@@ -540,6 +580,10 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
   }
   if (t == 0) a.status[reach] = status;
   if (a.ds.kind == FS_BC_STORAGE && t == tD) a.Yprev[reach] = Yprev;
+#ifdef FS_STAMP
+  if (a.dbg && lane == 0)
+    for (int i = 0; i < 8; ++i) a.dbg[((size_t)reach * 16 + wave) * 8 + i] = stamp_[i];
+#endif
 }
 
 }  // namespace fs
