@@ -55,7 +55,7 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),   \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true),                                           \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),   \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
@@ -64,6 +64,7 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
 const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
 #else

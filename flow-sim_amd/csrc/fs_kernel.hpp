@@ -31,6 +31,9 @@
 #ifndef FS_CELL_FENCE
 #define FS_CELL_FENCE 1
 #endif
+#ifndef FS_LEVEL_FENCE
+#define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
+#endif
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
@@ -143,10 +146,14 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
 };
 
 // LDS carve-up for one reach
+// W == 8 (512 threads, N up to 4097 at M = 8): the level-0 records of the in-wave tree stay in
+// registers (20 per lane) so that the LDS slots of levels 1..5 (31 per wave) fit next to kc.
+template <int W> struct TreeCfg { static constexpr bool kL0Regs = (W >= 8); static constexpr int kSlots = kL0Regs ? 32 : 64; };
+
 template <typename R, int M, int W> struct Smem {
   static constexpr int T = 64 * W;
   R kc[4][M][T];           // per-cell level-k constants, lane-minor (conflict-free ds_read_b64)
-  R tree[W][10][64];       // per-wave spill slots of the in-wave tree (63 used)
+  R tree[W][10][TreeCfg<W>::kSlots];   // per-wave spill slots of the in-wave tree
   R xseg[2][W][10];        // wave segments, double-buffered by iteration parity
   R xbc[2][8];             // boundary rows: U(dh,dq,res) D(dh,dq,res)
   R xnorm[2][W];
@@ -202,6 +209,9 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
       sm.kc[2][c][t] = hthk * sumA;
       sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (L.Se + Rn.Se);
       L = Rn;
+#if FS_LEVEL_FENCE
+      if ((c % FS_LEVEL_FENCE) == FS_LEVEL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
 
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
           }
           L = Rn;
 #if FS_CELL_FENCE
-          __builtin_amdgcn_sched_barrier(0);
+          if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
       }
@@ -407,6 +417,9 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
 
       FS_T(1);
       // ================= 3. in-wave tree (up-sweep) =================
+      constexpr bool L0R = TreeCfg<W>::kL0Regs;
+      constexpr int TS = TreeCfg<W>::kSlots;
+      Elim<R> e_l0;                     // level-0 record (odd lanes), only when L0R
 #pragma unroll
       for (int l = 0; l < 6; ++l) {
         const int d = 1 << l;
@@ -414,10 +427,14 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         Seg<R> mg; Elim<R> e;
         merge(left, seg, mg, e);
         if ((lane & (2 * d - 1)) == (2 * d - 1)) {
-          const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
-          R *p = &sm.tree[wave][0][slot];
-          p[0 * 64] = e.w10; p[1 * 64] = e.w11; p[2 * 64] = e.w20; p[3 * 64] = e.w21; p[4 * 64] = e.pm0;
-          p[5 * 64] = e.pm1; p[6 * 64] = e.qm;  p[7 * 64] = e.sc0; p[8 * 64] = e.sc1; p[9 * 64] = e.qc;
+          if (L0R && l == 0) {
+            e_l0 = e;
+          } else {
+            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (lane >> (l + 1));
+            R *p = &sm.tree[wave][0][slot];
+            p[0 * TS] = e.w10; p[1 * TS] = e.w11; p[2 * TS] = e.w20; p[3 * TS] = e.w21; p[4 * TS] = e.pm0;
+            p[5 * TS] = e.pm1; p[6 * TS] = e.qm;  p[7 * TS] = e.sc0; p[8 * TS] = e.sc1; p[9 * TS] = e.qc;
+          }
           seg = mg;
         }
       }
@@ -477,11 +494,15 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
         if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
         R m0 = R(0), m1 = R(0);
         if ((lane & (2 * d - 1)) == (2 * d - 1)) {
-          const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
-          const R *p = &sm.tree[wave][0][slot];
           Elim<R> e;
-          e.w10 = p[0 * 64]; e.w11 = p[1 * 64]; e.w20 = p[2 * 64]; e.w21 = p[3 * 64]; e.pm0 = p[4 * 64];
-          e.pm1 = p[5 * 64]; e.qm = p[6 * 64];  e.sc0 = p[7 * 64]; e.sc1 = p[8 * 64]; e.qc = p[9 * 64];
+          if (L0R && l == 0) {
+            e = e_l0;
+          } else {
+            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (lane >> (l + 1));
+            const R *p = &sm.tree[wave][0][slot];
+            e.w10 = p[0 * TS]; e.w11 = p[1 * TS]; e.w20 = p[2 * TS]; e.w21 = p[3 * TS]; e.pm0 = p[4 * TS];
+            e.pm1 = p[5 * TS]; e.qm = p[6 * TS];  e.sc0 = p[7 * TS]; e.sc1 = p[8 * TS]; e.qc = p[9 * TS];
+          }
           back(e, e0, e1, dR0, dR1, m0, m1);
         }
         const R x0 = shfl_dn_(m0, d), x1 = shfl_dn_(m1, d);
