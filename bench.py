@@ -34,7 +34,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achi
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, the unit this kernel actually runs on
 
 
-from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect  # noqa: E402
+from flowsim_amd.synthetic import (c3_reach_parameters, c5_reach_parameters, inflow_table,  # noqa: E402
+                                   normal_depth_rect, normal_depth_trap)
 from flowsim_amd.shard import gather_hydrographs, reach_block  # noqa: E402
 
 
@@ -79,6 +80,9 @@ def main():
     ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU")
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3: rectangular, normal-depth outflow (the headline config); c5: SURVEY 8d trapezoid + power "
+                         "rating curve (use with --dtype f32 --nodes 512 --reaches 131072)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -108,18 +112,33 @@ def main():
             dist.init_process_group(args.backend)
 
     B, N, K, Wm = args.reaches, args.nodes, args.steps, args.warmup
-    theta, dt, dx, tol = 0.6, 600.0, 250.0, 1e-6
     levels = K + Wm + 1
     first, _ = reach_block(rank, world, B)
-    b_, n_, S0, Qb = c3_reach_parameters(first, B)
-    hn = normal_depth_rect(b_, n_, S0, Qb)
-    L = (N - 1) * dx
-
-    batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="rect_uniform", device=local)
-    batch.set_scheme(theta, dt, dx, tol, 100)
-    batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
+    if args.workload == "c3":
+        theta, dt, dx, tol = 0.6, 600.0, 250.0, 1e-6
+        b_, n_, S0, Qb = c3_reach_parameters(first, B)
+        hn = normal_depth_rect(b_, n_, S0, Qb)
+        L = (N - 1) * dx
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="rect_uniform", device=local)
+        batch.set_scheme(theta, dt, dx, tol, 100)
+        batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
+        batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
+        desc = ("C3: %d synthetic rectangular reaches x %d nodes per GPU, constant Manning n, flow-hydrograph upstream, "
+                "normal-depth downstream, theta 0.6, dt 600 s, dx 250 m, tol 1e-6" % (B, N))
+    else:
+        theta, dt, dx = 0.6, 1800.0, 500.0
+        tol = 1e-3 if args.dtype == "f32" else 1e-6
+        b_, m_, n_, S0, Qb = c5_reach_parameters(first, B)
+        hn = normal_depth_trap(b_, m_, n_, S0, Qb)
+        L = (N - 1) * dx
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="trap_uniform", device=local)
+        batch.set_scheme(theta, dt, dx, tol, 100)
+        batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B), side_slope=m_)
+        batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_RATING_POWER, dict(a=Qb / hn ** 1.6, b=np.full(B, 1.6),
+                                                                            stage_shift=np.zeros(B), bed_level=np.zeros(B))))
+        desc = ("C5: %d synthetic trapezoidal reaches x %d nodes per GPU, power rating-curve downstream, theta 0.6, "
+                "dt 1800 s, dx 500 m, tol %g" % (B, N, tol))
     batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
-    batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
     batch.set_state_uniform(hn, Qb)
     batch.sync()
 
@@ -184,8 +203,7 @@ def main():
             "value": total / el, "unit": "reach-timesteps/s", "n_gpus": world, "steps": K, "warmup": Wm,
             "ms_per_step": el * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C3: {B} synthetic rectangular reaches x {N} nodes per GPU, constant Manning n, "
-                                   "flow-hydrograph upstream, normal-depth downstream, theta 0.6, dt 600 s, dx 250 m, tol 1e-6",
+            "config": {"workload": desc,
                        "reaches_per_gpu": B, "nodes": N, "parallelism": f"reach-sharded x{world}",
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
                        "kernel": info},
@@ -196,7 +214,7 @@ def main():
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
                          "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
         print(json.dumps(out), flush=True)
     batch.close()

@@ -56,6 +56,9 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),   \
+  FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1),          \
+  FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1),          \
+  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 16, 4),  \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
@@ -81,7 +84,7 @@ const Entry *pick_kernel(int dtype, int sec, int N, bool light_bc, std::string *
     const int cap = 64 * e.W * e.M;
     if (cap < cells) continue;
     if (e.full && !(cells == cap || cells == cap - 1)) continue;
-    if (e.bcfast && !light_bc) continue;
+    if (e.bcfast && (!light_bc || sec != FS_SEC_RECT_UNIFORM)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the select-free variant
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
@@ -194,7 +197,8 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     fail("fs_batch_create: need n_reaches >= 1, n_nodes >= 2, max_levels >= 2"); return nullptr;
   }
   if (desc->dtype != FS_F64 && desc->dtype != FS_F32) { fail("fs_batch_create: bad dtype"); return nullptr; }
-  if (desc->section_mode != FS_SEC_RECT_UNIFORM && desc->section_mode != FS_SEC_TABLE) {
+  if (desc->section_mode != FS_SEC_RECT_UNIFORM && desc->section_mode != FS_SEC_TRAP_UNIFORM &&
+      desc->section_mode != FS_SEC_TABLE) {
     fail("fs_batch_create: bad section_mode"); return nullptr;
   }
   if (fs_device_count() <= desc->device || desc->device < 0) {
@@ -268,12 +272,15 @@ int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double 
 
 int fs_batch_set_geometry_uniform(fs_batch *b, const double *params) {
   if (!b || !params) return fail("fs_batch_set_geometry_uniform: null argument");
-  if (b->d.section_mode != FS_SEC_RECT_UNIFORM) return fail("fs_batch_set_geometry_uniform: batch was created with another section_mode");
+  const bool trap = b->d.section_mode == FS_SEC_TRAP_UNIFORM;
+  if (b->d.section_mode != FS_SEC_RECT_UNIFORM && !trap) return fail("fs_batch_set_geometry_uniform: batch was created with another section_mode");
   const size_t B = b->d.n_reaches;
-  for (size_t i = 0; i < B; ++i)
+  for (size_t i = 0; i < B; ++i) {
     if (!(params[FS_RU_WIDTH * B + i] > 0) || !(params[FS_RU_MANNING * B + i] > 0))
       return fail("fs_batch_set_geometry_uniform: width and Manning n must be positive");
-  if (upload(b, &b->geo_uniform, params, (size_t)FS_RU_NPARAM * B)) return -1;
+    if (trap && !(params[FS_TU_SIDE_SLOPE * B + i] >= 0)) return fail("fs_batch_set_geometry_uniform: side slope must be >= 0");
+  }
+  if (upload(b, &b->geo_uniform, params, (size_t)(trap ? FS_TU_NPARAM : FS_RU_NPARAM) * B)) return -1;
   b->have_geo = true;
   return 0;
 }

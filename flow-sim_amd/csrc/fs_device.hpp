@@ -149,6 +149,34 @@ __device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q
   return t;
 }
 
+// Simple trapezoid fast path (cross_section.py:641-645): T = b + 2 m h, A = (b + m h) h,
+// P = b + 2 h sqrt(1 + m^2).  dK/dA / K = (1 + (2/3)(1 - 2 s A / (T P))) / A with s = sqrt(1+m^2)
+// (cross_section.py:756-790, hydraulics.py:28-40); one reciprocal of A*P*T serves 1/A, 1/P, 1/T.
+template <typename R>
+__device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R h, R Q) {
+  NodeTerms<R> t;
+  const R mh = m * h;
+  const R T = __builtin_fma(R(2), mh, b);
+  const R A = (b + mh) * h;
+  const R P = __builtin_fma(sm2, h, b);          // sm2 = 2 sqrt(1 + m^2)
+  const R AP = A * P;
+  const R r3 = frcp(AP * T);
+  const R rA = r3 * (P * T), rP = r3 * (A * T), rT = r3 * AP;
+  const R Rh = A * rP;
+  const R y = rcbrt_pos(Rh);
+  const R nk = n * rA * (y * y);
+  const R iK2 = nk * nk;
+  const R aQ = fabs_(Q);
+  t.A = A;
+  t.T = T;
+  t.Se = Q * aQ * iK2;
+  t.eQ = R(2) * aQ * iK2;
+  const R f = R(1) + R(2.0 / 3.0) * (R(1) - sm2 * A * rT * rP);
+  t.eA = R(-2) * t.Se * f * rA * T;
+  t.v = Q * rA;
+  return t;
+}
+
 // conveyance of a single sub-section, hydraulics.py:15-26
 template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * pow_(Rh, R(2.0 / 3.0)) / n; }
 

@@ -108,6 +108,39 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   }
 };
 
+template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
+  static constexpr bool kConstT = false;
+  R b, m, sm2, n, z_us, z_ds, inv_nm1, dz;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+    b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
+    n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
+    z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach];
+    z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
+    m = a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach];
+    sm2 = R(2) * sqrt_(R(1) + m * m);
+    inv_nm1 = R(1) / R(a.N - 1);
+    dz = (z_ds - z_us) * inv_nm1;
+  }
+  __device__ __forceinline__ R bed_step(int) const { return dz; }
+  __device__ __forceinline__ R terms_T() const { return R(0); }      // unused (kConstT == false)
+  __device__ __forceinline__ R bed(int node) const {
+    const R w2 = R(node) * inv_nm1;
+    return z_us * (R(1) - w2) + z_ds * w2;
+  }
+  __device__ __forceinline__ NodeTerms<R> terms(int, R h, R Q) const { return node_terms_trap(b, m, sm2, n, h, Q); }
+  __device__ __forceinline__ SecParams<R> section(int node) const {
+    SecParams<R> s;
+    s.z = bed(node); s.b = b; s.m = m; s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
+    s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
+    return s;
+  }
+  template <bool BCFAST>
+  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
+                                               R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+  }
+};
+
 template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   static constexpr bool kConstT = false;
   const R *tab;

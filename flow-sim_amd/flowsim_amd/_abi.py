@@ -11,8 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libflowsim_hip.so")
 
 F64, F32 = 0, 1
-SEC_RECT_UNIFORM, SEC_TABLE = 0, 2
+SEC_RECT_UNIFORM, SEC_TRAP_UNIFORM, SEC_TABLE = 0, 1, 2
 RU_WIDTH, RU_MANNING, RU_Z_US, RU_Z_DS, RU_NPARAM = 0, 1, 2, 3, 4
+TU_SIDE_SLOPE, TU_NPARAM = 4, 5
 GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
             "b_fp_l", "b_fp_r", "m_fp", "curvature")
 GEO_NPARAM = len(GEO_ROWS)

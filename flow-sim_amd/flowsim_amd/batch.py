@@ -45,7 +45,8 @@ class PreissmannBatch:
                  section_mode: str = "rect_uniform", device: int = 0, history: bool = False):
         self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
         self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
-        self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "table": A.SEC_TABLE}[section_mode]
+        self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "trap_uniform": A.SEC_TRAP_UNIFORM,
+                     "table": A.SEC_TABLE}[section_mode]
         self._lib = A.lib()
         desc = A.BatchDesc(self.B, self.N, self.dtype, self.mode, device, self.L,
                            A.FLAG_HISTORY if history else 0, 0)
@@ -77,9 +78,12 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_set_scheme(self._h, float(theta), float(dt), float(dx), float(tolerance),
                                               int(max_iter)), "set_scheme")
 
-    def set_geometry_uniform(self, width, manning, z_us, z_ds):
-        p = np.empty((A.RU_NPARAM, self.B), dtype=np.float64)
+    def set_geometry_uniform(self, width, manning, z_us, z_ds, side_slope=None):
+        trap = self.mode == A.SEC_TRAP_UNIFORM
+        p = np.empty((A.TU_NPARAM if trap else A.RU_NPARAM, self.B), dtype=np.float64)
         p[A.RU_WIDTH], p[A.RU_MANNING], p[A.RU_Z_US], p[A.RU_Z_DS] = width, manning, z_us, z_ds
+        if trap:
+            p[A.TU_SIDE_SLOPE] = 0.0 if side_slope is None else side_slope
         A.check(self._lib.fs_batch_set_geometry_uniform(self._h, _dptr(p)), "set_geometry_uniform")
 
     def set_geometry_table(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):

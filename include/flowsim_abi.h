@@ -40,14 +40,19 @@ enum { FS_F64 = 0, FS_F32 = 1 };
 /* How node geometry reaches the kernel.
  *   RECT_UNIFORM : one rectangular prismatic channel per reach from per-reach scalars
  *                  (what Channel(width=, roughness=) builds, channel.py:282-294);
+ *   TRAP_UNIFORM : one simple (non-compound) trapezoidal prismatic channel per reach from
+ *                  per-reach scalars (two TrapezoidalSection(z_bank=None) end sections with equal
+ *                  b_main / m_main / n_main, cross_section.py:641-645; BASELINE configs[4]);
  *   TABLE        : one [FS_GEO_NPARAM][N] table of TrapezoidalSection parameters at the nodes
  *                  (cross_section.py:569-613 after interpolation, channel.py:213-241), shared by
  *                  all reaches, optional per-reach main-channel Manning n
  *                  (cases/gerd_roseires/custom_functions.py:147). */
-enum { FS_SEC_RECT_UNIFORM = 0, FS_SEC_TABLE = 2 };
+enum { FS_SEC_RECT_UNIFORM = 0, FS_SEC_TRAP_UNIFORM = 1, FS_SEC_TABLE = 2 };
 
 /* rows of the RECT_UNIFORM parameter block, each [B] */
 enum { FS_RU_WIDTH = 0, FS_RU_MANNING = 1, FS_RU_Z_US = 2, FS_RU_Z_DS = 3, FS_RU_NPARAM = 4 };
+/* rows of the TRAP_UNIFORM parameter block, each [B]: the four above + the side slope m (H:V) */
+enum { FS_TU_SIDE_SLOPE = 4, FS_TU_NPARAM = 5 };
 
 /* rows of the TABLE geometry block, each [N] (TrapezoidalSection attributes) */
 enum {
@@ -102,7 +107,7 @@ void fs_batch_destroy(fs_batch *b);
  * (preissmann.py:23-46, :101; solver.py:32, :53-55) - shared by the whole batch */
 int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double tolerance, int32_t max_iter);
 
-/* RECT_UNIFORM: params[FS_RU_NPARAM][B] */
+/* RECT_UNIFORM: params[FS_RU_NPARAM][B];  TRAP_UNIFORM: params[FS_TU_NPARAM][B] */
 int fs_batch_set_geometry_uniform(fs_batch *b, const double *params);
 /* TABLE: table[FS_GEO_NPARAM][N]; n_main_override[B] or NULL */
 int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *n_main_override);

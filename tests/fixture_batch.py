@@ -48,8 +48,10 @@ def merge_specs(specs, B):
 
 def is_rect_uniform(p: O.Problem):
     g = p.geo
+    # interpolated n / b of a prismatic channel can differ by an ulp from node to node (n*w1 + n*w2)
+    flat = lambda a: np.ptp(a) <= 1e-13 * np.max(np.abs(a))
     return (np.all(g["is_compound"] < 0.5) and np.all(g["m_main"] == 0) and np.all(g["curvature"] == 0)
-            and np.ptp(g["b_main"]) == 0 and np.ptp(g["n_main"]) == 0)
+            and flat(g["b_main"]) and flat(g["n_main"]))
 
 
 def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main_override=None):
@@ -58,6 +60,9 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     B = len(problems)
     if mode == "auto":
         mode = "rect_uniform" if all(is_rect_uniform(p) for p in problems) else "table"
+        if mode == "table" and B > 1:
+            assert all(all(np.array_equal(p.geo[k], p0.geo[k]) for k in O.GEO_KEYS) for p in problems), \
+                "TABLE geometry is shared by the batch: reaches with their own channel need their own batch"
     b = PreissmannBatch(B, p0.N, p0.nt, dtype=dtype, section_mode=mode, history=history)
     b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
     if mode == "rect_uniform":
