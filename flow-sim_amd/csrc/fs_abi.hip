@@ -458,6 +458,43 @@ int fs_batch_get_storage_stages(fs_batch *b, int32_t first, int32_t n, double *o
   return download(b, out, b->stage_hist, (size_t)first * B, (size_t)n * B);
 }
 
+int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double *area, double *top_width,
+                    double *froude, double *velocity, double *celerity, double *amplitude, double *peak_amplitude) {
+  if (!b) return fail("null handle");
+  if (!b->hist_h) return fail("fs_batch_derive: batch was created without FS_FLAG_HISTORY");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_derive: level range out of bounds");
+  const size_t BN = (size_t)b->d.n_reaches * b->d.n_nodes;
+  double *host[8] = {level, area, top_width, froude, velocity, celerity, amplitude, peak_amplitude};
+  void *dev[8] = {nullptr};
+  int rc = 0;
+  for (int f = 0; f < 8 && !rc; ++f)
+    if (host[f] && hipMalloc(&dev[f], (f == 7 ? BN : BN * n) * b->esz) != hipSuccess) rc = fail("fs_batch_derive: hipMalloc failed");
+  if (!rc) {
+    const dim3 grid((unsigned)((BN + 255) / 256));
+    hipEventRecord(b->ev0, b->stream);      // fs_batch_last_step_ms() then reports this kernel
+    if (b->d.dtype == FS_F64) {
+      fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
+                               (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
+                               (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
+                               (double *)dev[5], (double *)dev[6], (double *)dev[7]};
+      hipLaunchKernelGGL((fs::derive_fields_kernel<double>), grid, dim3(256), 0, b->stream, a);
+    } else {
+      fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
+                              (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
+                              (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
+                              (float *)dev[5], (float *)dev[6], (float *)dev[7]};
+      hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);
+    }
+    hipEventRecord(b->ev1, b->stream);
+    b->timed = true; b->launches = 1;
+    if (hipGetLastError() != hipSuccess) rc = fail("fs_batch_derive: launch failed");
+    for (int f = 0; f < 8 && !rc; ++f)
+      if (host[f]) rc = download(b, host[f], dev[f], 0, f == 7 ? BN : BN * n);
+  }
+  for (void *p : dev) if (p) hipFree(p);
+  return rc;
+}
+
 void *fs_batch_hydrograph_device_ptr(fs_batch *b) { return b ? b->hydro : nullptr; }
 void *fs_batch_stream(fs_batch *b) { return b ? (void *)b->stream : nullptr; }
 

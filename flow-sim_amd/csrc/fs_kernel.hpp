@@ -31,6 +31,9 @@
 #ifndef FS_CELL_FENCE
 #define FS_CELL_FENCE 1
 #endif
+#ifndef FS_WPE_W1
+#define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
+#endif
 #ifndef FS_LEVEL_FENCE
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
@@ -201,7 +204,7 @@ template <typename R, int M, int W> struct Smem {
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rp0, rp1, rq, qc; };   // lives in AGPRs
 
 template <typename R, int SEC, int M, int W, bool RAGGED = true, bool BCFAST = false>
-__global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;
@@ -638,6 +641,70 @@ __global__ __launch_bounds__(64 * W) void preissmann_step_kernel(const KernelArg
   if (a.dbg && lane == 0)
     for (int i = 0; i < 8; ++i) a.dbg[((size_t)reach * 16 + wave) * 8 + i] = stamp_[i];
 #endif
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Post-processing (reference: Solver.prepare_results, solver.py:65-127).  One thread per
+// (reach, node) walks the stored levels: consecutive threads touch consecutive nodes, every
+// load / store is coalesced, 16 B in and up to 56 B out per element - a plain HBM-bound stream.
+// ---------------------------------------------------------------------------------------------
+template <typename R> struct DeriveArgs {
+  int32_t B, N, first, n, section_mode;
+  const R *hist_h, *hist_Q;       // [levels][B][N]
+  const R *geo_uniform, *geo_table;
+  R *level, *area, *top, *froude, *vel, *cel, *amp, *peak;   // [n][B][N] (peak: [B][N]) or nullptr
+};
+
+template <typename R> __global__ void derive_fields_kernel(const DeriveArgs<R> a) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t BN = (size_t)a.B * a.N;
+  if (i >= BN) return;
+  const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
+  SecParams<R> s;
+  if (a.section_mode == FS_SEC_TABLE) {
+    auto g = [&](int row) { return a.geo_table[(size_t)row * a.N + node]; };
+    s.z = g(FS_GEO_Z_BED); s.b = g(FS_GEO_B_MAIN); s.m = g(FS_GEO_M_MAIN);
+    s.compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
+    s.hbf = g(FS_GEO_H_BANKFULL); s.bl = g(FS_GEO_B_FP_LEFT); s.br = g(FS_GEO_B_FP_RIGHT); s.mfp = g(FS_GEO_M_FP);
+  } else {
+    const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
+    const R w2 = R(node) / R(a.N - 1);
+    s.z = z_us * (R(1) - w2) + z_ds * w2;
+    s.b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
+    s.m = a.section_mode == FS_SEC_TRAP_UNIFORM ? a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach] : R(0);
+    s.compound = false; s.hbf = s.bl = s.br = s.mfp = R(0);
+  }
+  const R h0 = a.hist_h[i];                 // depth[0] (amplitude reference, solver.py:96-97)
+  R peak = R(-3.0e38);
+  for (int k = 0; k < a.n; ++k) {
+    const size_t src = (size_t)(a.first + k) * BN + i, dst = (size_t)k * BN + i;
+    const R h = a.hist_h[src], Q = a.hist_Q[src];
+    // area and top width: cross_section.py:623-679 (incl. the over-bank convention)
+    const R d = fmax_(R(0), h);
+    R T = s.b + R(2) * s.m * d;
+    R A = (s.b + T) / R(2) * d;
+    if (s.compound && d > s.hbf) {
+      const R dfp = d - s.hbf, Tb = s.b + R(2) * s.m * s.hbf;
+      A = (s.b + Tb) / R(2) * s.hbf + (s.bl + R(0.5) * s.mfp * dfp) * dfp + (s.br + R(0.5) * s.mfp * dfp) * dfp;
+      T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
+    }
+    if (d <= R(0)) { A = R(0); T = R(0); }
+    const R V = Q / A;
+    if (a.level) a.level[dst] = h + s.z;
+    if (a.area) a.area[dst] = A;
+    if (a.top) a.top[dst] = T;
+    if (a.froude) {                          // hydraulics.py:155-168 with its clamps
+      const R Vc = Q / fmax_(A, R(1e-6)), D = A / fmax_(T, R(1e-6));
+      a.froude[dst] = Vc / sqrt_(R(kG) * fmax_(D, R(1e-6)));
+    }
+    if (a.vel) a.vel[dst] = V;
+    if (a.cel) a.cel[dst] = V + sqrt_(R(kG) * A / T);
+    const R am = h - h0;
+    if (a.amp) a.amp[dst] = am;
+    peak = fmax_(peak, am);
+  }
+  if (a.peak) a.peak[i] = peak;
 }
 
 }  // namespace fs

@@ -59,6 +59,7 @@ SIGNATURES = {
     "fs_batch_get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D]),
     "fs_batch_get_storage_stage": (C.c_int, [_P, _D]),
     "fs_batch_get_storage_stages": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
+    "fs_batch_derive": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D, _D, _D, _D, _D, _D]),
     "fs_batch_hydrograph_device_ptr": (_P, [_P]),
     "fs_batch_stream": (_P, [_P]),
     "fs_batch_last_step_ms": (C.c_double, [_P]),

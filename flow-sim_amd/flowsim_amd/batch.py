@@ -191,6 +191,21 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_get_storage_stages(self._h, first, n, _dptr(out)), "get_storage_stages")
         return out
 
+    DERIVED = ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity", "amplitude")
+
+    def derive(self, first=0, n=None, fields=None):
+        """Solver.prepare_results on the device (needs history=True): dict name -> [n, B, N] plus
+        peak_amplitude [B, N]."""
+        n = self.level + 1 - first if n is None else n
+        want = set(self.DERIVED + ("peak_amplitude",)) if fields is None else set(fields)
+        out = {k: np.empty((n, self.B, self.N)) for k in self.DERIVED if k in want}
+        if "peak_amplitude" in want:
+            out["peak_amplitude"] = np.empty((self.B, self.N))
+        ptr = lambda k: _dptr(out[k]) if k in out else None
+        A.check(self._lib.fs_batch_derive(self._h, first, n, *[ptr(k) for k in self.DERIVED], ptr("peak_amplitude")),
+                "derive")
+        return out
+
     def last_step_ms(self):
         return self._lib.fs_batch_last_step_ms(self._h)
 

@@ -61,6 +61,8 @@ class PreissmannSolver(Solver):
             h, Q = b.history_arrays(0, max(nt, 2))
             gh, gQ = b.guess()
             stages = b.storage_stages(0, max(nt, 2))[:nt, 0] if ch.downstream_boundary.lumped_storage is not None else None
+            self._derived = {k: v[:, 0] if v.ndim == 3 else v[0] for k, v in b.derive(0, nt).items()} \
+                if status == A.OK and nt > 1 else None
         self.iterations = its
         self.unknowns = np.empty(2 * N)
         self.unknowns[0::2], self.unknowns[1::2] = gh[0], gQ[0]

@@ -82,14 +82,14 @@ class Solver(ABC):
             self.flow, self.depth = self.flow[:k + 1], self.depth[:k + 1]
         geo = self.channel.node_geometry
         self.bed_profile = np.array(geo["z_bed"], dtype=np.float64)
-        self.level = self.depth + self.bed_profile
-        A, P, R, T, _ = XS.props({n: v[None, :] for n, v in geo.items()}, self.level)
-        self.area, self.top_width = A, T
-        self.froude_number = hydraulics.froude_array(T, A, self.flow)
-        self.velocity = self.flow / self.area
-        self.wave_celerity = self.velocity + np.sqrt(hydraulics.g * self.area / self.top_width)
-        self.amplitude = self.depth - self.depth[0, :]
-        self.peak_amplitude = self.amplitude.max(axis=0)
+        dev = getattr(self, "_derived", None)
+        if dev is not None and dev["level"].shape == self.depth.shape:
+            # computed by the elementwise HIP kernel behind fs_batch_derive right after the run
+            for name in ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity", "amplitude",
+                         "peak_amplitude"):
+                setattr(self, name, dev[name])
+        else:
+            self.prepare_results_host()
         st = self.channel.downstream_boundary.lumped_storage
         if st is not None:
             # level 0 stage = initial interface stage (no entrance losses in the supported configuration)
@@ -101,6 +101,18 @@ class Solver(ABC):
             dvol = np.array([st.net_vol_change(Y1=a, Y2=b) for a, b in zip(self.storage_stage[:-1], self.storage_stage[1:])])
             out[1:] = (qin - dvol / self.time_step) * self.flow[1:, -1] / qin
             self.storage_outflow = out
+
+    def prepare_results_host(self):
+        """the same fields with numpy (used when no device history is available, e.g. after a failed run)"""
+        geo = self.channel.node_geometry
+        self.level = self.depth + self.bed_profile
+        A, P, R, T, _ = XS.props({n: v[None, :] for n, v in geo.items()}, self.level)
+        self.area, self.top_width = A, T
+        self.froude_number = hydraulics.froude_array(T, A, self.flow)
+        self.velocity = self.flow / self.area
+        self.wave_celerity = self.velocity + np.sqrt(hydraulics.g * self.area / self.top_width)
+        self.amplitude = self.depth - self.depth[0, :]
+        self.peak_amplitude = self.amplitude.max(axis=0)
 
     def save_results(self, folder_path: str, file_name: str = None) -> None:
         raise NotImplementedError("the xlsx writer is outside the accelerated path (SURVEY.md section 2); "

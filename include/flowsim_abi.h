@@ -150,6 +150,15 @@ int fs_batch_get_storage_stage(fs_batch *b, double *out);
  * rows of levels that have not been computed (and level 0) are 0 */
 int fs_batch_get_storage_stages(fs_batch *b, int32_t first_level, int32_t n_levels, double *out);
 
+/* Solver.prepare_results (solver.py:65-127) for levels [first, first+n) of the stored history
+ * (FS_FLAG_HISTORY): level = depth + bed, area, top width, Froude number (hydraulics.py:155-168),
+ * velocity Q/A, wave celerity V + sqrt(g A / T), amplitude = depth - depth[0]; each [n][B][N], and
+ * peak_amplitude [B][N] = max over those levels.  Any output pointer may be NULL.  One elementwise,
+ * HBM-bound kernel; results are copied to the caller's host arrays. */
+int fs_batch_derive(fs_batch *b, int32_t first_level, int32_t n_levels, double *level, double *area,
+                    double *top_width, double *froude, double *velocity, double *celerity,
+                    double *amplitude, double *peak_amplitude);
+
 /* zero-copy access for device-side consumers (RCCL gather of hydrographs): device pointer to the
  * [max_levels][4][B] hydrograph block in the batch dtype, and the handle's hipStream_t */
 void *fs_batch_hydrograph_device_ptr(fs_batch *b);

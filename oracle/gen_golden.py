@@ -107,6 +107,14 @@ def run_and_capture(solver, tolerance, max_iter=100):
         final_unknowns=np.array(solver.unknowns, dtype=np.float64),
     )
     out.update({"geo_" + k: v for k, v in section_soa(solver.channel).items()})
+    # post-processing of the reference (Solver.prepare_results, solver.py:65-127) on the stored solution
+    from src.hydromodel.solver import Solver
+    Solver.prepare_results(solver)
+    for name in ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity", "amplitude", "peak_amplitude"):
+        out["derived_" + name] = np.array(getattr(solver, name), dtype=np.float64)
+    if hasattr(solver, "storage_outflow"):
+        out["derived_storage_outflow"] = np.array(solver.storage_outflow, dtype=np.float64)
+        out["derived_storage_stage"] = np.array(solver.storage_stage, dtype=np.float64)
     return out, wall
 
 
@@ -207,7 +215,7 @@ def case_example():
                            simulation_time=24 * 3600)
     out, wall = run_and_capture(sol, 1e-4)
     out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
-    out["storage_stage"] = np.array(ss.stage_hydrograph, dtype=np.float64)   # [k-1] -> (t, stage)
+    out["storage_stage"] = np.array(ss.stage_hydrograph, dtype=np.float64)[1:]   # level k -> (t, stage); [0] is the t=0 row prepare_results inserted
     save("example", out, base_meta(sol, 1e-4, wall, width=250, roughness=0.027,
                                    storage_area=5000.0 * 250, storage_min_stage=5.0,
                                    storage_bounds=[0, 200], ds_initial_depth=5.0))
@@ -460,6 +468,9 @@ def case_gerd(steps):
     save("gerd", out, base_meta(sol, S.tolerance, wall, rating=rating_spec(rc, rr),
                                 ds_initial_depth=float(sol.channel.downstream_boundary.initial_depth)))
 
+    if os.environ.get("GEN_SKIP_ENSEMBLE"):
+        os.chdir(os.path.dirname(os.path.abspath(__file__)))
+        return
     # Manning-n ensemble: the n_calibrate.py:5-17 setup (small inflow table, no curvature, 32 steps)
     members = np.linspace(0.020, 0.060, 8)
     stack = {}

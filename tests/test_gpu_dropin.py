@@ -79,3 +79,19 @@ def test_manning_ensemble_batch_matches_sequential_reference_runs():
                                                   (fx["depth"], -1, 1e-3), (fx["flow"], -1, 1.0))):
             assert rel(hy[:, col], arr[i][:, node], floor) <= TOL, (i, col)
         assert np.array_equal(res["iterations"][:, i], fx["iters"][i])
+
+
+@pytest.mark.parametrize("name", ["akbari", "example", "bc_compound_normal", "gerd"])
+def test_derived_fields_kernel_matches_reference_post_processing(name):
+    """fs_batch_derive (HIP, elementwise) vs the reference's Solver.prepare_results output."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, tol = CB.BUILDERS[name]()
+    solver.run(tolerance=tol, verbose=0)
+    assert solver._derived is not None
+    for field in ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity"):
+        assert rel(getattr(solver, field), fx["derived_" + field], 1e-6) <= TOL, field
+    np.testing.assert_allclose(solver.amplitude, fx["derived_amplitude"], rtol=0, atol=1e-8 * np.abs(fx["depth"]).max())
+    np.testing.assert_allclose(solver.peak_amplitude, fx["derived_peak_amplitude"], rtol=0, atol=1e-8 * np.abs(fx["depth"]).max())
+    if "derived_storage_outflow" in fx.files:
+        assert rel(solver.storage_stage, fx["derived_storage_stage"], 1e-3) <= TOL
+        np.testing.assert_allclose(solver.storage_outflow, fx["derived_storage_outflow"], rtol=1e-6, atol=1e-4)

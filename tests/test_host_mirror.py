@@ -103,3 +103,18 @@ def test_roseires_rating_curve_matches_reference_samples():
     assert kind == "blend"
     np.testing.assert_allclose([p["lo0"], p["lo1"], p["lo2"]], meta["rating"]["low"], rtol=1e-12)
     np.testing.assert_allclose([p["hi0"], p["hi1"], p["hi2"]], meta["rating"]["high"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["akbari", "example", "bc_compound_normal", "gerd"])
+def test_prepare_results_host_fields(name):
+    """Solver.prepare_results (solver.py:65-127) in numpy, fed with the reference's own depth/flow."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, _ = CB.BUILDERS[name]()
+    solver.depth[:], solver.flow[:] = fx["depth"], fx["flow"]
+    solver.time_level = meta["nt"] - 1
+    solver.bed_profile = np.array(solver.channel.node_geometry["z_bed"])
+    solver.prepare_results_host()
+    for mine, ref in (("level", "level"), ("area", "area"), ("top_width", "top_width"), ("froude_number", "froude_number"),
+                      ("velocity", "velocity"), ("wave_celerity", "wave_celerity"), ("amplitude", "amplitude"),
+                      ("peak_amplitude", "peak_amplitude")):
+        np.testing.assert_allclose(getattr(solver, mine), fx["derived_" + ref], rtol=1e-12, atol=1e-12, err_msg=mine)
