@@ -238,3 +238,48 @@ def test_fp32_rectangular_tracks_the_fp64_reference():
     for i in range(len(probs)):
         assert rel_err(h[:, i], fx["depth"][i], 1e-3) <= 5e-4
         assert rel_err(Q[:, i], fx["flow"][i], 1.0) <= 5e-4
+
+
+def test_full_size_batch_properties():
+    """BASELINE configs[2] size (65 536 reaches x 4 096 nodes, fp64) through size-independent
+    properties: (i) 256 distinct channels replicated 256 times give bitwise identical copies,
+    (ii) identical to the 256-reach batch, (iii) every reach converges, (iv) mass balance of the
+    routed wave: inflow - outflow volume equals the change of storage to 1e-9 of the inflow volume."""
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+    from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
+    N, K, dt, dx = 4096, 6, 600.0, 250.0
+    b0, n0, S0, Qb0 = c3_reach_parameters(0, 256)
+    hn0 = normal_depth_rect(b0, n0, S0, Qb0)
+    L = (N - 1) * dx
+
+    def run(rep):
+        b, n, S, Qb, hn = (np.tile(v, rep) for v in (b0, n0, S0, Qb0, hn0))
+        B = 256 * rep
+        bt = PreissmannBatch(B, N, K + 1, section_mode="rect_uniform")
+        bt.set_scheme(0.6, dt, dx, 1e-6, 100)
+        bt.set_geometry_uniform(b, n, S * L, np.zeros(B))
+        bt.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, K + 1, dt)))
+        bt.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S, bed_level=np.zeros(B))))
+        bt.set_state_uniform(hn, Qb)
+        bt.step(K)
+        out = bt.hydrographs(), bt.iterations(), bt.status(), bt.state()
+        bt.close()
+        return out
+
+    hyd1, it1, st1, (h1, Q1) = run(1)
+    hyd, it, st, (h, Q) = run(256)
+    assert np.all(st == 0) and np.all(st1 == 0)
+    assert np.array_equal(hyd.reshape(K + 1, 4, 256, 256), np.broadcast_to(hyd1[:, :, None, :], (K + 1, 4, 256, 256)))
+    assert np.array_equal(it.reshape(K + 1, 256, 256), np.broadcast_to(it1[:, None, :], (K + 1, 256, 256)))
+    assert np.array_equal(h.reshape(256, 256, N), np.broadcast_to(h1[None], (256, 256, N)))
+    # continuity of the scheme: trapezoidal inflow/outflow volumes vs stored volume (rectangular: A = b h)
+    vol_in = dt * (0.5 * (hyd1[:-1, 1] + hyd1[1:, 1])).sum(axis=0)
+    vol_out = dt * (0.5 * (hyd1[:-1, 3] + hyd1[1:, 3])).sum(axis=0)
+    w = np.full(N, dx); w[0] = w[-1] = dx / 2
+    stored = (b0[:, None] * (h1 - hn0[:, None]) * w[None, :]).sum(axis=1)
+    th = 0.6     # the box scheme conserves the theta-weighted fluxes; compare at the scheme's own weighting
+    q_in = th * hyd1[1:, 1] + (1 - th) * hyd1[:-1, 1]
+    q_out = th * hyd1[1:, 3] + (1 - th) * hyd1[:-1, 3]
+    net = dt * (q_in - q_out).sum(axis=0)
+    assert np.max(np.abs(net - stored) / vol_in) <= 1e-9
