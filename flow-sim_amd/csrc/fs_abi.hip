@@ -238,8 +238,8 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     if ((e = hipMalloc(&b->hist_Q, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
   }
 #ifdef FS_STAMP
-  if ((e = hipMalloc((void **)&b->dbg, B * 16 * 8 * 8)) != hipSuccess) return bad("hipMalloc(dbg)", e);
-  hipMemsetAsync(b->dbg, 0, B * 16 * 8 * 8, b->stream);
+  if ((e = hipMalloc((void **)&b->dbg, B * 16 * 12 * 8)) != hipSuccess) return bad("hipMalloc(dbg)", e);
+  hipMemsetAsync(b->dbg, 0, B * 16 * 12 * 8, b->stream);
 #endif
   hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
   hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);

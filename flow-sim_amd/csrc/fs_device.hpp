@@ -19,13 +19,21 @@ constexpr double kG = 9.80665;  // scipy.constants.g (hydraulics.py:2)
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------------
+#ifndef FS_RCP_NR
+#define FS_RCP_NR 1
+#endif
 __device__ __forceinline__ double frcp(double x) {
-  // v_rcp_f64 seed + two Newton steps: ~1 ulp for normal, finite x (all our operands)
+  // v_rcp_f64 seed (measured on gfx950: 2^-24.4 relative, tools/micro/rcp_prec.hip) + Newton steps:
+  // one step leaves <= 2.3e-15 relative (~10 ulp), two steps are correctly rounded.  The kernel's
+  // reciprocals feed Jacobian entries and friction terms whose effect on the accepted iterate is
+  // orders below the 1e-8 parity bar, so one step is the default.
   double r = __builtin_amdgcn_rcp(x);
-  double e = __builtin_fma(-x, r, 1.0);
-  r = __builtin_fma(r, e, r);
-  e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(r, e, r);
+#pragma unroll
+  for (int i = 0; i < FS_RCP_NR; ++i) {
+    const double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+  }
+  return r;
 }
 __device__ __forceinline__ float frcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);

@@ -34,6 +34,9 @@
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
 #endif
+#ifndef FS_CONST_VGPR
+#define FS_CONST_VGPR 0     // pin hot uniform constants in VGPRs (measured: no gain)
+#endif
 #ifndef FS_LEVEL_FENCE
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
@@ -71,7 +74,7 @@ template <typename R> struct KernelArgs {
   int32_t *iters;          // [levels][B]
   int32_t *status;         // [B]
   R *hist_h, *hist_Q;      // [levels][B][N] or nullptr
-  unsigned long long *dbg; // diagnostic builds (-DFS_STAMP): [B][W][8] cycle sums per phase, else nullptr
+  unsigned long long *dbg; // diagnostic builds (-DFS_STAMP): [B][16][12] cycle sums per phase, else nullptr
 };
 
 template <typename R, int SEC> struct Geometry;
@@ -221,11 +224,17 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   geo.init(a, reach);
 
   const R th = a.theta, dt = a.dt;
-  const R r2dt = R(1) / (R(2) * dt);
-  const R cq = th / a.dx;                     // theta/dx
+  R r2dt = R(1) / (R(2) * dt);
+  R cq = th / a.dx;                           // theta/dx
   const R cqk = (R(1) - th) / a.dx;           // (1-theta)/dx
-  const R hth = R(0.5) * th, hthk = R(0.5) * (R(1) - th);
-  const R g = R(kG);
+  R hth = R(0.5) * th;
+  const R hthk = R(0.5) * (R(1) - th);
+  R g = R(kG);
+#if FS_CONST_VGPR
+  // The hot uniform constants are pinned in VGPRs: as SGPRs they are spilled to VGPR lanes under the
+  // scalar-register pressure of this kernel and re-read with two v_readlane per use (~240 per iteration).
+  asm volatile("" : "+v"(r2dt), "+v"(cq), "+v"(hth), "+v"(g));
+#endif
 
   // ---- unknowns of this lane: nodes s0 .. s0+M (clamped copies beyond the last node) ----
   R h[M + 1], Q[M + 1];
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
     write_level_constants(hk, Qk);
   }
 #ifdef FS_STAMP
-  unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
   for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
@@ -593,18 +602,25 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           a.iters[(size_t)level * a.B + reach] = it;
         }
         {
-          // (a transposed, fully coalesced write-back through LDS was measured: no gain, three extra barriers)
+          // Level k+1 is rebuilt from registers, so the accepted state only has to reach HBM when
+          // somebody can look at it: at the last level of this launch (fs_batch_get_state, next launch)
+          // and, if a history is kept, at every level.  (A transposed, fully coalesced write-back
+          // through LDS was measured too: no gain, three extra barriers.)
+          const bool last = (step == a.n_steps - 1);
           R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
           R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          if (last || hh_p) {
 #pragma unroll
-          for (int j = 0; j <= M; ++j) {
-            const int node = s0 + j;
-            if ((j < M || node == N - 1) && node < N) {
-              hk_p[j] = h[j]; Qk_p[j] = Q[j];
-              if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
+            for (int j = 0; j <= M; ++j) {
+              const int node = s0 + j;
+              if ((j < M || node == N - 1) && node < N) {
+                if (last) { hk_p[j] = h[j]; Qk_p[j] = Q[j]; }
+                if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
+              }
             }
           }
         }
+        FS_T(8);
         if (t == tD) {
 #pragma unroll
           for (int j = 1; j <= M; ++j)
@@ -619,7 +635,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
 #pragma unroll
           for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
         }
+        FS_T(9);
         write_level_constants(h, Q);                                  // level constants of the next level
+        FS_T(10);
       }
 
       FS_T(5);
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   if (a.ds.kind == FS_BC_STORAGE && t == tD) a.Yprev[reach] = Yprev;
 #ifdef FS_STAMP
   if (a.dbg && lane == 0)
-    for (int i = 0; i < 8; ++i) a.dbg[((size_t)reach * 16 + wave) * 8 + i] = stamp_[i];
+    for (int i = 0; i < 12; ++i) a.dbg[((size_t)reach * 16 + wave) * 12 + i] = stamp_[i];
 #endif
 }
 

@@ -133,7 +133,10 @@ int fs_batch_step(fs_batch *b, int32_t n_steps);
 int fs_batch_sync(fs_batch *b);
 int32_t fs_batch_level(const fs_batch *b);   /* current time level k */
 
-/* depth[k], flow[k] of the current level (what update_guesses stored, preissmann.py:166-177) */
+/* depth[k], flow[k] of the current level (what update_guesses stored, preissmann.py:166-177).
+ * The kernel writes the accepted state to HBM at the last level of each fs_batch_step call (and at
+ * every level into the history when FS_FLAG_HISTORY is set); for a reach whose status is not FS_OK
+ * this is therefore the state at the end of the previous call. */
 int fs_batch_get_state(fs_batch *b, double *h, double *Q);
 /* the post-update Newton vector that seeds the next level (preissmann.py:146-147) */
 int fs_batch_get_guess(fs_batch *b, double *h, double *Q);
