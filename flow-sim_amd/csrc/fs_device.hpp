@@ -506,11 +506,47 @@ template <typename R> __device__ __forceinline__ R shfl_up_(R v, int d) { return
 template <typename R> __device__ __forceinline__ R shfl_dn_(R v, int d) { return __shfl_down(v, d, 64); }
 template <typename R> __device__ __forceinline__ R shfl_(R v, int l) { return __shfl(v, l, 64); }
 
-template <typename R> __device__ __forceinline__ Seg<R> seg_shfl_up(const Seg<R> &s, int d) {
+// Cross-lane moves without the LDS crossbar: DPP modifiers on v_mov_b32 (gfx9 family).
+//   row_shr:n / row_shl:n  move within a row of 16 lanes; row_bcast15 / row_bcast31 hand lane 15 of
+//   each row to the next row / lane 31 to rows 2-3.  The tree only ever needs lane-d for a lane
+//   whose low bits are all ones, which these patterns cover for every stride (see fs_kernel.hpp).
+#ifndef FS_DPP
+#define FS_DPP 1
+#endif
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = dpp_mov<CTRL>(__double2loint(v)), hi = dpp_mov<CTRL>(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
+}
+// value of lane - D for lanes whose low log2(2D) bits are all ones (others: unspecified)
+template <int D, typename R> __device__ __forceinline__ R tree_from_below(R v) {
+#if FS_DPP
+  if (D < 16) return dpp_mov<0x110 + (D < 16 ? D : 1)>(v);      // row_shr:D
+  if (D == 16) return dpp_mov<0x142>(v);                          // row_bcast15
+  return dpp_mov<0x143>(v);                                       // row_bcast31
+#else
+  return __shfl_up(v, D, 64);
+#endif
+}
+// value of lane + D for lanes with (lane & (2D-1)) == D-1 (others: unspecified)
+template <int D, typename R> __device__ __forceinline__ R tree_from_above(R v) {
+#if FS_DPP
+  if (D < 16) return dpp_mov<0x100 + (D < 16 ? D : 1)>(v);      // row_shl:D
+#endif
+  return __shfl_down(v, D, 64);
+}
+
+template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(const Seg<R> &s) {
   Seg<R> o;
-  o.pc0 = shfl_up_(s.pc0, d); o.pc1 = shfl_up_(s.pc1, d); o.sc0 = shfl_up_(s.sc0, d); o.sc1 = shfl_up_(s.sc1, d);
-  o.qc = shfl_up_(s.qc, d); o.pm0 = shfl_up_(s.pm0, d); o.pm1 = shfl_up_(s.pm1, d); o.sm0 = shfl_up_(s.sm0, d);
-  o.sm1 = shfl_up_(s.sm1, d); o.qm = shfl_up_(s.qm, d);
+  o.pc0 = tree_from_below<D>(s.pc0); o.pc1 = tree_from_below<D>(s.pc1); o.sc0 = tree_from_below<D>(s.sc0);
+  o.sc1 = tree_from_below<D>(s.sc1); o.qc = tree_from_below<D>(s.qc); o.pm0 = tree_from_below<D>(s.pm0);
+  o.pm1 = tree_from_below<D>(s.pm1); o.sm0 = tree_from_below<D>(s.sm0); o.sm1 = tree_from_below<D>(s.sm1);
+  o.qm = tree_from_below<D>(s.qm);
   return o;
 }
 template <typename R> __device__ __forceinline__ R wave_sum(R v) {

@@ -22,6 +22,7 @@
 // padding and the per-cell padding selects (and their 64-bit lane masks) disappear;
 // BCFAST = true (RECT_UNIFORM only) inlines the boundary rows and requires bc_is_light() kinds.
 #pragma once
+#include <type_traits>
 #include "fs_device.hpp"
 
 // build-time experiment switches (defaults = the configuration that measured fastest)
@@ -465,10 +466,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       constexpr bool L0R = TreeCfg<W>::kL0Regs;
       constexpr int TS = TreeCfg<W>::kSlots;
       Elim<R> e_l0;                     // level-0 record (odd lanes), only when L0R
-#pragma unroll
-      for (int l = 0; l < 6; ++l) {
-        const int d = 1 << l;
-        const Seg<R> left = seg_shfl_up(seg, d);
+      auto up_level = [&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int d = 1 << l;
+        const Seg<R> left = seg_from_below<d>(seg);
         Seg<R> mg; Elim<R> e;
         merge(left, seg, mg, e);
         if ((lane & (2 * d - 1)) == (2 * d - 1)) {
@@ -482,7 +483,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           }
           seg = mg;
         }
-      }
+      };
+      up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
+      up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
+      up_level(std::integral_constant<int, 4>{}); up_level(std::integral_constant<int, 5>{});
       nrm2 = wave_sum(nrm2);
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
@@ -532,9 +536,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       FS_T(5);
       // ================= 6. separators down the tree, local back-substitution, update ============
       R dR0 = bR0, dR1 = bR1;       // valid on lane 63; filled for every lane below
-#pragma unroll
-      for (int l = 5; l >= 0; --l) {
-        const int d = 1 << l;
+      auto down_level = [&](auto lc) {
+        constexpr int l = decltype(lc)::value;
+        constexpr int d = 1 << l;
+        // left end of the merged pair: lane - 2d (a lane with all low bits set), or the wave's left boundary
+        // (lane - 2d can sit in the previous DPP row, so this one fetch stays a ds_bpermute)
         R e0 = shfl_up_(dR0, 2 * d), e1 = shfl_up_(dR1, 2 * d);
         if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
         R m0 = R(0), m1 = R(0);
@@ -550,9 +556,12 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           }
           back(e, e0, e1, dR0, dR1, m0, m1);
         }
-        const R x0 = shfl_dn_(m0, d), x1 = shfl_dn_(m1, d);
+        const R x0 = tree_from_above<d>(m0), x1 = tree_from_above<d>(m1);
         if ((lane & (2 * d - 1)) == (d - 1)) { dR0 = x0; dR1 = x1; }
-      }
+      };
+      down_level(std::integral_constant<int, 5>{}); down_level(std::integral_constant<int, 4>{});
+      down_level(std::integral_constant<int, 3>{}); down_level(std::integral_constant<int, 2>{});
+      down_level(std::integral_constant<int, 1>{}); down_level(std::integral_constant<int, 0>{});
       R dL0 = shfl_up_(dR0, 1), dL1 = shfl_up_(dR1, 1);
       if (lane == 0) { dL0 = bL0; dL1 = bL1; }
 
