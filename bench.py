@@ -39,8 +39,10 @@ from flowsim_amd.synthetic import (c3_reach_parameters, c5_reach_parameters, inf
 from flowsim_amd.shard import gather_hydrographs, reach_block  # noqa: E402
 
 
-def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
-    """Oracle port on one host core, same workload definition, bounded sample."""
+def cpu_baseline(N, dt, dx, theta, tol, budget_s=9.0, compiled=False):
+    """Oracle port on one host core, same workload definition, bounded sample.  compiled=False: the
+    numpy + scipy.sparse.linalg.spsolve port (the reference's own solver call); compiled=True: the
+    plain-C restatement with its banded LU (oracle/preissmann_oracle.c)."""
     try:
         import psutil
         psutil.Process().cpu_affinity([psutil.Process().cpu_affinity()[0]])
@@ -48,6 +50,8 @@ def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
         pass
     os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import preissmann_oracle as O
+    if compiled:
+        from oracle import c_oracle as CO
     b, n, S0, Qb = c3_reach_parameters(0, 1024)
     hn = normal_depth_rect(b, n, S0, Qb)
     steps = 4
@@ -63,13 +67,14 @@ def cpu_baseline(N, dt, dx, theta, tol, budget_s=12.0):
                       us=O.BC("flow_hydrograph", bed_level=S0[r] * L, target=tgt[:, r].copy()),
                       ds=O.BC("normal_depth", bed_level=0.0, bed_slope=float(S0[r])),
                       theta=theta, dt=dt, dx=dx, nt=steps + 1, tol=tol)
-        O.newton_run(p)
+        (CO.run if compiled else O.newton_run)(p)
         done += steps
         if time.perf_counter() - t0 > budget_s:
             break
     el = time.perf_counter() - t0
     return {"value": done / el, "unit": "reach-timesteps/s", "cores": 1, "kind": "port",
-            "sample": f"{done // steps} reaches x {N} nodes x {steps} steps, numpy+scipy.spsolve oracle, {el:.1f} s"}
+            "sample": f"{done // steps} reaches x {N} nodes x {steps} steps, "
+                      + ("C oracle (gcc -O2, banded LU)" if compiled else "numpy+scipy.spsolve oracle") + f", {el:.1f} s"}
 
 
 def main():
@@ -216,6 +221,7 @@ def main():
         }
         if not args.no_cpu_baseline and args.workload == "c3":
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
+            out["cpu_baseline_c"] = cpu_baseline(N, dt, dx, theta, tol, compiled=True)
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:

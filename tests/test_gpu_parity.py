@@ -283,3 +283,21 @@ def test_full_size_batch_properties():
     q_out = th * hyd1[1:, 3] + (1 - th) * hyd1[:-1, 3]
     net = dt * (q_in - q_out).sum(axis=0)
     assert np.max(np.abs(net - stored) / vol_in) <= 1e-9
+
+
+def test_sixteen_full_width_reaches_against_the_c_oracle():
+    """N = 4096, 16 different channels, 6 levels: HIP path vs the compiled CPU oracle."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle as CO
+    from synth import rect_problem
+    probs = [rect_problem(4096, seed=100 + s, n_steps=6) for s in range(16)]
+    with batch_from_problems(probs, mode="rect_uniform") as b:
+        b.step(6)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+        assert np.all(b.status() == 0)
+    for i, p in enumerate(probs):
+        out = CO.run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL
+        assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL
+        assert np.array_equal(its[:, i], out["iters"])
