@@ -115,7 +115,7 @@ struct fs_batch {
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
   void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
-  void *Yprev = nullptr, *stage_hist = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
+  void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
   int32_t *iters = nullptr, *status = nullptr;
   unsigned long long *dbg = nullptr;
 };
@@ -172,7 +172,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
     bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
     bc[s]->params = (const R *)b->bc_params[s]; bc[s]->target = (const R *)b->bc_target[s];
   }
-  a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
+  a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.trace = (R *)b->trace; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
   a.dbg = b->dbg;
 }
@@ -233,6 +233,10 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc(&b->Yprev, B * b->esz)) != hipSuccess) return bad("hipMalloc(Yprev)", e);
   if ((e = hipMalloc(&b->stage_hist, L * B * b->esz)) != hipSuccess) return bad("hipMalloc(stage_hist)", e);
   hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream);
+  if (desc->flags & FS_FLAG_TRACE) {
+    if ((e = hipMalloc(&b->trace, L * FS_TRACE_CAP * B * b->esz)) != hipSuccess) return bad("hipMalloc(trace)", e);
+    hipMemsetAsync(b->trace, 0, L * FS_TRACE_CAP * B * b->esz, b->stream);
+  }
   if (desc->flags & FS_FLAG_HISTORY) {
     if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
     if ((e = hipMalloc(&b->hist_Q, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
@@ -253,7 +257,7 @@ void fs_batch_destroy(fs_batch *b) {
   if (!b) return;
   if (b->stream) hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
-                  b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->hydro, b->hist_h, b->hist_Q,
+                  b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status};
   for (void *p : bufs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
@@ -337,6 +341,7 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->status, 0, B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
+  if (b->trace) HIP_TRY(hipMemsetAsync(b->trace, 0, (size_t)b->d.max_levels * FS_TRACE_CAP * B * b->esz, b->stream));
   b->level = 0;
   b->have_state = true;
   return 0;
@@ -449,6 +454,14 @@ int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, doubl
 int fs_batch_get_storage_stage(fs_batch *b, double *out) {
   if (!b || !out) return fail("fs_batch_get_storage_stage: null argument");
   return download(b, out, b->Yprev, 0, b->d.n_reaches);
+}
+
+int fs_batch_get_residual_trace(fs_batch *b, int32_t first, int32_t n, double *out) {
+  if (!b || !out) return fail("fs_batch_get_residual_trace: null argument");
+  if (!b->trace) return fail("fs_batch_get_residual_trace: batch was created without FS_FLAG_TRACE");
+  if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_residual_trace: level range out of bounds");
+  const size_t per = (size_t)FS_TRACE_CAP * b->d.n_reaches;
+  return download(b, out, b->trace, first * per, n * per);
 }
 
 int fs_batch_get_storage_stages(fs_batch *b, int32_t first, int32_t n, double *out) {

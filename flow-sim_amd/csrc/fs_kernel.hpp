@@ -75,6 +75,7 @@ template <typename R> struct KernelArgs {
   int32_t *iters;          // [levels][B]
   int32_t *status;         // [B]
   R *hist_h, *hist_Q;      // [levels][B][N] or nullptr
+  R *trace;                // [levels][FS_TRACE_CAP][B] residual norms or nullptr
   unsigned long long *dbg; // diagnostic builds (-DFS_STAMP): [B][16][12] cycle sums per phase, else nullptr
 };
 
@@ -532,6 +533,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       if (sm.xflag[parity] != 0) status = sm.xflag[parity];
       if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
       converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
+      if (a.trace && t == 0 && it <= FS_TRACE_CAP)
+        a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
 
       FS_T(5);
       // ================= 6. separators down the tree, local back-substitution, update ============

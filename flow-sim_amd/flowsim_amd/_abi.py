@@ -21,7 +21,8 @@ GEO_NPARAM = len(GEO_ROWS)
  BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE) = range(8)
 UPSTREAM, DOWNSTREAM = 0, 1
 OK, MAX_ITER, NAN, STORAGE_RANGE = 0, 1, 2, 3
-FLAG_HISTORY = 1
+FLAG_HISTORY, FLAG_TRACE = 1, 2
+TRACE_CAP = 64
 ABI_VERSION = 1
 
 
@@ -57,6 +58,7 @@ SIGNATURES = {
     "fs_batch_get_iterations": (C.c_int, [_P, C.c_int32, C.c_int32, _I]),
     "fs_batch_get_status": (C.c_int, [_P, _I]),
     "fs_batch_get_history": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D]),
+    "fs_batch_get_residual_trace": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
     "fs_batch_get_storage_stage": (C.c_int, [_P, _D]),
     "fs_batch_get_storage_stages": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
     "fs_batch_derive": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D, _D, _D, _D, _D, _D]),

@@ -42,14 +42,14 @@ def _dptr(a):
 
 class PreissmannBatch:
     def __init__(self, n_reaches: int, n_nodes: int, max_levels: int, dtype: str = "f64",
-                 section_mode: str = "rect_uniform", device: int = 0, history: bool = False):
+                 section_mode: str = "rect_uniform", device: int = 0, history: bool = False, trace: bool = False):
         self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
         self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
         self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "trap_uniform": A.SEC_TRAP_UNIFORM,
                      "table": A.SEC_TABLE}[section_mode]
         self._lib = A.lib()
         desc = A.BatchDesc(self.B, self.N, self.dtype, self.mode, device, self.L,
-                           A.FLAG_HISTORY if history else 0, 0)
+                           (A.FLAG_HISTORY if history else 0) | (A.FLAG_TRACE if trace else 0), 0)
         self._h = self._lib.fs_batch_create(C.byref(desc))
         if not self._h:
             raise A.FlowsimError(A.last_error())
@@ -182,6 +182,13 @@ class PreissmannBatch:
     def storage_stage(self):
         out = np.empty(self.B)
         A.check(self._lib.fs_batch_get_storage_stage(self._h, _dptr(out)), "get_storage_stage")
+        return out
+
+    def residual_trace(self, first=0, n=None):
+        """[n, TRACE_CAP, B] ||R|| per Newton iteration (needs trace=True); zeros beyond a level's count."""
+        n = self.level + 1 - first if n is None else n
+        out = np.empty((n, A.TRACE_CAP, self.B))
+        A.check(self._lib.fs_batch_get_residual_trace(self._h, first, n, _dptr(out)), "get_residual_trace")
         return out
 
     def storage_stages(self, first=0, n=None):

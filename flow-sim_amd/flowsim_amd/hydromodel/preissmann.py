@@ -45,7 +45,7 @@ class PreissmannSolver(Solver):
                 and np.ptp(geo["b_main"]) == 0 and np.ptp(geo["n_main"]) == 0 and ch.input_xs is not None
                 and len(ch.input_xs) == 2)
         with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode="rect_uniform" if rect else "table",
-                             history=True) as b:
+                             history=True, trace=(verbose == 3)) as b:
             b.set_scheme(self.theta, self.time_step, self.spatial_step, tolerance, max_iter)
             if rect:
                 b.set_geometry_uniform(geo["b_main"][0], geo["n_main"][0], geo["z_bed"][0], geo["z_bed"][-1])
@@ -60,6 +60,7 @@ class PreissmannSolver(Solver):
             its = b.iterations(0, max(nt, 2))[:nt, 0]
             h, Q = b.history_arrays(0, max(nt, 2))
             gh, gQ = b.guess()
+            self.residual_norms = b.residual_trace(0, max(nt, 2))[:nt, :, 0] if verbose == 3 else None
             stages = b.storage_stages(0, max(nt, 2))[:nt, 0] if ch.downstream_boundary.lumped_storage is not None else None
             self._derived = {k: v[:, 0] if v.ndim == 3 else v[0] for k, v in b.derive(0, nt).items()} \
                 if status == A.OK and nt > 1 else None
@@ -83,10 +84,13 @@ class PreissmannSolver(Solver):
         st = ch.downstream_boundary.lumped_storage
         if st is not None:
             st.stage_hydrograph = [[k * self.time_step, float(stages[k])] for k in range(1, nt)]
-        if verbose >= 1:
+        if verbose >= 1:      # same lines as the reference prints while it runs (preissmann.py:116-159)
             for k in range(1, nt):
                 print(f'\n> Time level #{k}')
-                if verbose >= 2:
+                if verbose == 3:
+                    for i in range(min(its[k], A.TRACE_CAP)):
+                        print(f">> Iteration #{i + 1}: Error = {self.residual_norms[k, i]}")
+                if verbose == 2:
                     print(f'>> {its[k]} iterations.')
         self._finalize(verbose)
 

@@ -82,7 +82,11 @@ enum { FS_UPSTREAM = 0, FS_DOWNSTREAM = 1 };
 /* per-reach status after stepping (preissmann.py:124-126 raises ValueError; :135-137 NaN check) */
 enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3 };
 
-enum { FS_FLAG_HISTORY = 1 };   /* keep depth/flow[level][B][N] on the device (solver.py:43-44) */
+enum {
+  FS_FLAG_HISTORY = 1,  /* keep depth/flow[level][B][N] on the device (solver.py:43-44) */
+  FS_FLAG_TRACE = 2     /* keep ||R|| of every Newton iteration (what run(verbose=3) prints, preissmann.py:149-152) */
+};
+#define FS_TRACE_CAP 64 /* iterations per level kept by FS_FLAG_TRACE */
 
 typedef struct fs_batch_desc {
   int32_t n_reaches;     /* B */
@@ -147,6 +151,9 @@ int fs_batch_get_iterations(fs_batch *b, int32_t first_level, int32_t n_levels, 
 int fs_batch_get_status(fs_batch *b, int32_t *out);                                            /* [B]   */
 /* FS_FLAG_HISTORY only: h, Q [n_levels][B][N] (solver.depth / solver.flow, solver.py:43-44) */
 int fs_batch_get_history(fs_batch *b, int32_t first_level, int32_t n_levels, double *h, double *Q);
+/* FS_FLAG_TRACE only: out[n_levels][FS_TRACE_CAP][B] residual norms, iteration i of level k at
+ * [k][i-1][reach]; entries beyond the iteration count of a level are 0 */
+int fs_batch_get_residual_trace(fs_batch *b, int32_t first_level, int32_t n_levels, double *out);
 /* reservoir stage kept per level by the storage boundary (boundary.py:126-131): out[B] */
 int fs_batch_get_storage_stage(fs_batch *b, double *out);
 /* the same per time level (LumpedStorage.stage_hydrograph, boundary.py:126-131): out[n_levels][B],

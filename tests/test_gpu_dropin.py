@@ -95,3 +95,21 @@ def test_derived_fields_kernel_matches_reference_post_processing(name):
     if "derived_storage_outflow" in fx.files:
         assert rel(solver.storage_stage, fx["derived_storage_stage"], 1e-3) <= TOL
         np.testing.assert_allclose(solver.storage_outflow, fx["derived_storage_outflow"], rtol=1e-6, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["akbari", "gerd", "example"])
+def test_newton_residual_trace_matches_reference(name, capsys):
+    """run(verbose=3) prints the reference's '>> Iteration #i: Error = ...' lines; the norms of every
+    Newton iteration of every level follow the reference's (quadratic convergence amplifies
+    rounding, so late iterates are compared against the size of the first residual)."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, tol = CB.BUILDERS[name]()
+    solver.run(tolerance=tol, verbose=3)
+    out = capsys.readouterr().out
+    assert out.count(">> Iteration #") == int(fx["iters"].sum())
+    lv, val = fx["norm_level"], fx["norm_value"]
+    for k in range(1, meta["nt"]):
+        ref = val[lv == k]
+        got = solver.residual_norms[k, :len(ref)]
+        assert np.all(solver.residual_norms[k, len(ref):] == 0)
+        np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-9 * ref[0] + 1e-12)
