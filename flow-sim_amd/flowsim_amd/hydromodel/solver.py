@@ -1,8 +1,8 @@
 """Solver: grid sizing, the depth/flow[nt, N] history, accessors and post-processing shared by
 the schemes (reference: src/hydromodel/solver.py:10-329).
 
-`save_results` (xlsx writer, needs openpyxl) is out of scope; the derived
-fields of `prepare_results` are computed here with numpy over whole [nt, N] arrays."""
+`prepare_results` takes its derived fields from the elementwise HIP kernel behind fs_batch_derive
+(numpy fallback for a failed run); `save_results` writes the reference's sheets and text summary."""
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -115,8 +115,68 @@ class Solver(ABC):
         self.peak_amplitude = self.amplitude.max(axis=0)
 
     def save_results(self, folder_path: str, file_name: str = None) -> None:
-        raise NotImplementedError("the xlsx writer is outside the accelerated path (SURVEY.md section 2); "
-                                  "read solver.depth / solver.flow and the prepare_results fields instead")
+        """Result tables + text summary (solver.py:129-233).  The reference writes one .xlsx workbook
+        through pandas/openpyxl; when openpyxl is not installed the same sheets go to a .npz archive
+        (one array per sheet) next to the identical .txt summary.  Windows path separators in
+        `folder_path` (the reference's case scripts use them) are accepted."""
+        import os
+        folder_path = folder_path.replace("\\", os.sep)
+        os.makedirs(folder_path, exist_ok=True)
+        file_name = 'results.xlsx' if file_name is None else file_name
+        file_path = os.path.join(folder_path, file_name)
+        sheets = {"Level": self.level, "Flow": self.flow, "Depth": self.depth, "Velocity": self.velocity,
+                  "Area": self.area, "Top width": self.top_width, "Wave celerity": self.wave_celerity,
+                  "Amplitude": self.amplitude, "Froude number": self.froude_number}
+        nt = self.depth.shape[0]
+        time = np.arange(nt) * self.time_step
+        distance = np.array(self.channel.ch_at_node, dtype=np.float64)
+        rows = {"Peak amplitude": self.peak_amplitude[None, :], "Bed level": self.bed_profile[None, :]}
+        storage = self.channel.downstream_boundary.lumped_storage is not None
+        try:
+            import openpyxl  # noqa: F401
+            import pandas as pd
+            with pd.ExcelWriter(file_path, engine="openpyxl") as writer:
+                for name, arr in sheets.items():
+                    df = pd.DataFrame(arr, index=time, columns=distance)
+                    df.index.name, df.columns.name = "Time", "Distance"
+                    df.to_excel(writer, sheet_name=name)
+                if storage:
+                    df = pd.DataFrame({"outflow": self.storage_outflow}, index=time)
+                    df.index.name = "Time"
+                    df.to_excel(writer, sheet_name="Outflow")
+                for name, arr in rows.items():
+                    df = pd.DataFrame(arr, columns=distance, index=[name])
+                    df.columns.name = "Distance"
+                    df.to_excel(writer, sheet_name=name)
+        except ImportError:
+            extra = {"Outflow": self.storage_outflow, "Reservoir stage": self.storage_stage} if storage else {}
+            np.savez(os.path.splitext(file_path)[0] + ".npz", Time=time, Distance=distance,
+                     **{k.replace(" ", "_"): v for k, v in {**sheets, **rows, **extra}.items()})
+        with open(os.path.splitext(file_path)[0] + '.txt', 'w') as out:
+            out.write(self.summary())
+
+    def summary(self) -> str:
+        """The text block of the reference's results file (solver.py:188-233): steps, duration, mass
+        imbalance, peak attenuation and median-volume travel time."""
+        from .utility import seconds_to_hms
+        q_in, q_out = np.asarray(self.flow)[:, 0], np.asarray(self.flow)[:, -1]
+        imbalance = np.sum(q_in - q_out) * self.time_step
+        pct = float(imbalance / self.time_step / np.sum(q_in)) * 100
+        peak_in, peak_out = np.max(q_in), np.max(q_out)
+
+        def median_time(q):
+            cum = np.concatenate([[0.0], np.cumsum(q)[:-1]])          # sum(q[:i]) for i = 0..n-1
+            return int(np.argmax(cum >= 0.5 * cum[-1])) * self.time_step
+        t_in, t_out = median_time(q_in), median_time(q_out)
+        lines = [f'Spatial step = {self.spatial_step} m', f'Time step = {self.time_step} s',
+                 f'Simulation duration = {seconds_to_hms(self.total_sim_duration)}',
+                 f'Mass imbalance (total inflow - total outflow) = {imbalance:.2f} m^3 = {pct:.4f}% of inflow.',
+                 f'Peak inflow = {peak_in:.2f} m^3/s', f'Peak outflow = {peak_out:.2f} m^3/s',
+                 f'Attenuation = {(peak_in - peak_out) / peak_in * 100:.2f}%',
+                 f'Median volume entry time = {seconds_to_hms(t_in)}',
+                 f'Median volume arrival time = {seconds_to_hms(t_out)}',
+                 f'Median volume travel time = {seconds_to_hms(t_out - t_in)}']
+        return "\n".join(lines) + "\n"
 
     def _finalize(self, verbose):
         self._solved = True

@@ -118,3 +118,26 @@ def test_prepare_results_host_fields(name):
                       ("velocity", "velocity"), ("wave_celerity", "wave_celerity"), ("amplitude", "amplitude"),
                       ("peak_amplitude", "peak_amplitude")):
         np.testing.assert_allclose(getattr(solver, mine), fx["derived_" + ref], rtol=1e-12, atol=1e-12, err_msg=mine)
+
+
+def test_save_results_summary_and_tables(tmp_path):
+    """save_results (solver.py:129-233): sheets + the text summary, fed with the reference's solution."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "example.npz"))
+    solver, _ = CB.example()
+    solver.depth[:], solver.flow[:] = fx["depth"], fx["flow"]
+    solver.time_level = meta["nt"] - 1
+    solver.total_sim_duration = solver.time_level * solver.time_step
+    st = solver.channel.downstream_boundary.lumped_storage
+    st.stage_hydrograph = [[float(t), float(v)] for t, v in fx["storage_stage"]]
+    solver._derived = None
+    solver.prepare_results()
+    np.testing.assert_allclose(solver.storage_outflow, fx["derived_storage_outflow"], rtol=1e-9, atol=1e-6)
+    folder = str(tmp_path / "cases") + "\\example\\results"          # Windows separators as in the reference's scripts
+    solver.save_results(folder_path=folder)
+    out_dir = folder.replace("\\", os.sep)
+    txt = open(os.path.join(out_dir, "results.txt")).read()
+    q_in, q_out = fx["flow"][:, 0], fx["flow"][:, -1]
+    assert f"Peak inflow = {q_in.max():.2f} m^3/s" in txt and f"Peak outflow = {q_out.max():.2f} m^3/s" in txt
+    assert f"Mass imbalance (total inflow - total outflow) = {np.sum(q_in - q_out) * 3600:.2f} m^3" in txt
+    assert "Median volume travel time = " in txt and "Simulation duration = 24:00:00" in txt
+    assert any(f.startswith("results.") and f.endswith((".xlsx", ".npz")) for f in os.listdir(out_dir))
