@@ -85,9 +85,10 @@ def main():
     ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU")
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c4"],
                     help="c3: rectangular, normal-depth outflow (the headline config); c5: SURVEY 8d trapezoid + power "
-                         "rating curve (use with --dtype f32 --nodes 512 --reaches 131072)")
+                         "rating curve (use with --dtype f32 --nodes 512 --reaches 131072); c4: cases/gerd_roseires "
+                         "geometry with a Manning-n Monte-Carlo ensemble (use with --reaches 32768; nodes fixed at 121)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -130,6 +131,27 @@ def main():
         batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
         desc = ("C3: %d synthetic rectangular reaches x %d nodes per GPU, constant Manning n, flow-hydrograph upstream, "
                 "normal-depth downstream, theta 0.6, dt 600 s, dx 250 m, tol 1e-6" % (B, N))
+    elif args.workload == "c4":
+        # BASELINE configs[3] / SURVEY 8d C4: gerd_roseires geometry shared by all members, n_main ~ U(0.02, 0.06)
+        from cases.gerd_roseires.model import build as build_gerd
+        from flowsim_amd.ensemble import gvf_profiles
+        from flowsim_amd.hydromodel.preissmann import boundary_to_spec
+        solver, _ = build_gerd(inflow_hyd_func=None, sim_duration=(levels - 1) * 3600)
+        ch = solver.channel
+        N = solver.number_of_nodes
+        rng = np.random.default_rng(20260215)
+        n_members = (0.020 + 0.040 * rng.random(first + B))[first:]
+        theta, dt, dx, tol = solver.theta, float(solver.time_step), solver.spatial_step, 1e-6
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="table", device=local)
+        batch.set_scheme(theta, dt, dx, tol, 100)
+        batch.set_geometry_table(ch.node_geometry, n_main_override=n_members)
+        batch.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, levels, dt))
+        batch.set_boundary(A.DOWNSTREAM, boundary_to_spec(ch.downstream_boundary, levels, dt))
+        ic = gvf_profiles(ch, n_members)
+        batch.set_state(ic[:, :, 0], ic[:, :, 1])
+        Qb = None
+        desc = ("C4: cases/gerd_roseires (121 nodes, compound sections + curvature, Roseires gate curve), %d-member "
+                "Manning-n ensemble per GPU, theta 0.6, dt 3600 s, tol 1e-6" % B)
     else:
         theta, dt, dx = 0.6, 1800.0, 500.0
         tol = 1e-3 if args.dtype == "f32" else 1e-6
@@ -143,8 +165,9 @@ def main():
                                                                             stage_shift=np.zeros(B), bed_level=np.zeros(B))))
         desc = ("C5: %d synthetic trapezoidal reaches x %d nodes per GPU, power rating-curve downstream, theta 0.6, "
                 "dt 1800 s, dx 500 m, tol %g" % (B, N, tol))
-    batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
-    batch.set_state_uniform(hn, Qb)
+    if args.workload != "c4":
+        batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
+        batch.set_state_uniform(hn, Qb)
     batch.sync()
 
     # device view of the hydrograph block for the RCCL gather (zero copy)

@@ -185,10 +185,15 @@ __device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R 
   return t;
 }
 
-// conveyance of a single sub-section, hydraulics.py:15-26
-template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * pow_(Rh, R(2.0 / 3.0)) / n; }
+// x^(2/3), x^(3/2), x^(-1/3) for x >= 0 without pow(): v_log/v_exp seeded x^(-1/3) and v_sqrt
+// (each within a few ulp of the reference's libm pow; 0 -> 0 as 0**p gives in the reference)
+template <typename R> __device__ __forceinline__ R p23_(R x) { return x > R(0) ? x * rcbrt_pos(x) : R(0); }
+template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ? x * sqrt_(x) : R(0); }
 
-template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA; };
+// conveyance of a single sub-section, hydraulics.py:15-26
+template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) / n; }
+
+template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA, y13; };
 
 // General trapezoid family (rectangle / simple / compound), straight from the reference including
 // the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
@@ -221,20 +226,21 @@ __device__ __noinline__ GeneralProps<R> general_props(const SecParams<R> s, R h)
     const R R_l = P_l > R(0) ? A_l / P_l : R(0);
     const R R_r = P_r > R(0) ? A_r / P_r : R(0);
     const R Kl = conv_(A_l, s.nl, R_l), Km = conv_(A_m, s.nm, R_m), Kr = conv_(A_r, s.nr, R_r);
-    K = pow_(pow_(Kl, R(1.5)) + pow_(Km, R(1.5)) + pow_(Kr, R(1.5)), R(2.0 / 3.0));   // :753
+    K = p23_(p32_(Kl) + p32_(Km) + p32_(Kr));                        // :753
     g.Rh = P > R(0) ? A / P : R(0);
   } else {
     g.Rh = P > R(0) ? A / P : R(0);
     K = conv_(A, s.nm, g.Rh);
-    if (s.compound) K = pow_(pow_(K, R(1.5)), R(2.0 / 3.0));     // the reference's round trip, :747-754
+    if (s.compound) K = p23_(p32_(K));                           // the reference's round trip, :747-754
   }
-  const R R23 = pow_(g.Rh, R(2.0 / 3.0));
+  const R y13 = g.Rh > R(0) ? rcbrt_pos(g.Rh) : R(0);            // R^(-1/3)
+  const R R23 = g.Rh * y13;
   R neq = s.nm;
   if (s.compound && A > R(0) && g.Rh > R(0) && K > R(0)) neq = A * R23 / K;     // :710-739
   g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * (R(1) / T))) / (P * P);   // :766-790
   g.dKdA = A <= R(0) ? R(0)
-                     : (R23 + A * R(2.0 / 3.0) * pow_(g.Rh, R(2.0 / 3.0 - 1.0)) * g.dRdA) / neq;  // :756-764
-  g.A = A; g.P = P; g.T = T; g.K = K; g.neq = neq;
+                     : (R23 + A * R(2.0 / 3.0) * y13 * g.dRdA) / neq;                              // :756-764
+  g.A = A; g.P = P; g.T = T; g.K = K; g.neq = neq; g.y13 = y13;
   return g;
 }
 
@@ -253,8 +259,7 @@ __device__ __noinline__ NodeTerms<R> node_terms_general(const SecParams<R> s, R 
     const R V = Q / fmax_(A, R(1e-6));                            // hydraulics.py:155-168
     const R D = A / fmax_(T, R(1e-6));
     const R Fr = V / sqrt_(R(kG) * fmax_(D, R(1e-6)));
-    const R C = pow_(Rh, R(1.0 / 6.0)) / g.neq;
-    const R f = R(8) * R(kG) / (C * C);                           // :217-229
+    const R f = R(8) * R(kG) * g.neq * g.neq * g.y13;             // 8 g / C^2 with C = R^(1/6)/n, :217-229
     const R sq = sqrt_(f);
     const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
     const R den = (R(0.565) + sq) * rc * rc;
@@ -262,13 +267,15 @@ __device__ __noinline__ NodeTerms<R> node_terms_general(const SecParams<R> s, R 
     if (fabs_(s.curv) > R(1e-12)) {
       const R gD = R(kG) * (A / T);
       const R Vr = Q / A;
-      const R dFrA = R(-0.5) * Vr * pow_(gD, R(-1.5)) * R(kG) * (R(1) / T) + (-Q / (A * A)) * pow_(gD, R(-0.5));
-      const R dfA = -(R(8.0 / 3.0)) * R(kG) * g.neq * g.neq * pow_(Rh, R(-4.0 / 3.0)) * g.dRdA;
+      const R rs = R(1) / sqrt_(gD), rs3 = rs * rs * rs;          // (gD)^-0.5, (gD)^-1.5
+      const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * (R(1) / T) + (-Q / (A * A)) * rs;
+      const R y2 = g.y13 * g.y13;
+      const R dfA = -(R(8.0 / 3.0)) * R(kG) * g.neq * g.neq * (y2 * y2) * g.dRdA;
       const R dnum = (R(2.86) / (R(2) * sq) * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
                      (R(2.86) * sq + R(2.07) * f) * (R(2) * h * (R(1) / T) * Fr * Fr + h * h * R(2) * Fr * dFrA);
       const R dden = (R(1) / (R(2) * sq) * dfA) * rc * rc;
       dSeA += (dnum * den - num * dden) / (den * den) * T;        // :119-137, x dA_dh (cross_section.py:164)
-      const R dFrQ = (R(1) / A) * pow_(gD, R(-0.5));
+      const R dFrQ = (R(1) / A) * rs;
       const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
       eQ += (dnumq * den) / (den * den);                          // :139-153
     }

@@ -141,3 +141,14 @@ def test_save_results_summary_and_tables(tmp_path):
     assert f"Mass imbalance (total inflow - total outflow) = {np.sum(q_in - q_out) * 3600:.2f} m^3" in txt
     assert "Median volume travel time = " in txt and "Simulation duration = 24:00:00" in txt
     assert any(f.startswith("results.") and f.endswith((".xlsx", ".npz")) for f in os.listdir(out_dir))
+
+
+def test_vectorised_gvf_profiles_match_per_member_setup():
+    """flowsim_amd.ensemble.gvf_profiles (all members at once) == Channel initial conditions member by
+    member == the reference's (tests/golden/gerd_ensemble.npz)."""
+    from flowsim_amd.ensemble import gvf_profiles
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "gerd_ensemble.npz"))
+    ns = fx["n_members"]
+    lead, _ = CB.gerd_member(float(ns[0]))
+    ic = gvf_profiles(lead.channel, ns)
+    np.testing.assert_allclose(ic, fx["initial_conditions"], rtol=1e-11, atol=1e-12)
