@@ -198,8 +198,16 @@ template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA, y
 // General trapezoid family (rectangle / simple / compound), straight from the reference including
 // the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
 // pow()-heavy and only the boundary rows and the TABLE geometry mode use it.
+#ifndef FS_GENERAL_INLINE
+#define FS_GENERAL_INLINE 1   // inline the general section evaluation into the fold (measured on C4: 4.5e6 -> 7.1e6)
+#endif
+#if FS_GENERAL_INLINE
+#define FS_GEN_ATTR __forceinline__
+#else
+#define FS_GEN_ATTR __noinline__
+#endif
 template <typename R>
-__device__ __noinline__ GeneralProps<R> general_props(const SecParams<R> s, R h) {
+__device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) {
   GeneralProps<R> g;
   const R d = fmax_(R(0), h);
   const R sm = sqrt_(R(1) + s.m * s.m);
@@ -244,8 +252,12 @@ __device__ __noinline__ GeneralProps<R> general_props(const SecParams<R> s, R h)
   return g;
 }
 
+// out-of-line copy for the boundary rows (executed by two lanes per reach: keep it out of the hot code)
 template <typename R>
-__device__ __noinline__ NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
+__device__ __noinline__ GeneralProps<R> general_props_call(const SecParams<R> s, R h) { return general_props(s, h); }
+
+template <typename R>
+__device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
   const GeneralProps<R> g = general_props(s, h);
   NodeTerms<R> t;
   const R iK2 = R(1) / (g.K * g.K);
@@ -329,8 +341,8 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
       const R S0 = p(0), bed = p(1);
       const R sg = S0 < R(0) ? R(-1) : R(1);
       const R rt = sqrt_(fabs_(S0));
-      const GeneralProps<R> gr = general_props(sec, h);                 // residual: hw = z_min + h
-      const GeneralProps<R> gd = general_props(sec, h + bed - sec.z);   // df_dh: hw = h + bed_level
+      const GeneralProps<R> gr = general_props_call(sec, h);                 // residual: hw = z_min + h
+      const GeneralProps<R> gd = general_props_call(sec, h + bed - sec.z);   // df_dh: hw = h + bed_level
       r.res = Q - sg * gr.K * rt;                                       // hydraulics.py:4-13
       r.dh = R(0) - sg * gd.dKdA * rt * gd.T;                           // hydraulics.py:206-215
       r.dq = R(1);
