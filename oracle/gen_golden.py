@@ -67,21 +67,36 @@ class Spy:
 
 
 def section_soa(channel):
-    """Flatten the per-node TrapezoidalSection objects (cross_section.py:569-613)."""
+    """Flatten the per-node section objects: TrapezoidalSection attributes (cross_section.py:569-613)
+    and, for IrregularSection nodes (cross_section.py:207-243), the polyline padded with NaN."""
     xs = channel.xs_at_node
-    def arr(f):
-        return np.array([f(s) for s in xs], dtype=np.float64)
-    return dict(
-        z_bed=arr(lambda s: s.z_bed), b_main=arr(lambda s: s.b_main), m_main=arr(lambda s: s.m_main),
-        n_main=arr(lambda s: s.n_main), n_left=arr(lambda s: s.n_left), n_right=arr(lambda s: s.n_right),
+    irr = [hasattr(s, "x") for s in xs]
+    def arr(f, g=lambda s: 0.0):
+        return np.array([g(s) if hasattr(s, "x") else f(s) for s in xs], dtype=np.float64)
+    out = dict(
+        z_bed=arr(lambda s: s.z_bed, lambda s: s.z_min), b_main=arr(lambda s: s.b_main), m_main=arr(lambda s: s.m_main),
+        n_main=arr(lambda s: s.n_main, lambda s: s.n_main), n_left=arr(lambda s: s.n_left, lambda s: s.n_left),
+        n_right=arr(lambda s: s.n_right, lambda s: s.n_right),
         is_compound=arr(lambda s: 1.0 if s._is_compound else 0.0),
         is_rect=arr(lambda s: 1.0 if s._is_rect else 0.0),
         h_bf=arr(lambda s: s.bankfull_depth if s._is_compound else 0.0),
         b_fp_l=arr(lambda s: s.b_fp_left), b_fp_r=arr(lambda s: s.b_fp_right), m_fp=arr(lambda s: s.m_fp),
-        curvature=arr(lambda s: s.curvature),
-        bed_slope=arr(lambda s: np.nan if s.bed_slope is None else s.bed_slope),
+        curvature=arr(lambda s: s.curvature, lambda s: s.curvature),
+        bed_slope=arr(lambda s: np.nan if s.bed_slope is None else s.bed_slope,
+                      lambda s: np.nan if s.bed_slope is None else s.bed_slope),
         chainage=np.asarray(channel.ch_at_node, dtype=np.float64),
     )
+    if any(irr):
+        P = max(s.x.size for s in xs if hasattr(s, "x"))
+        X = np.full((len(xs), P), np.nan); Z = np.full((len(xs), P), np.nan)
+        cnt = np.zeros(len(xs), dtype=np.int32)
+        lim = np.zeros((len(xs), 2))
+        for i, s in enumerate(xs):
+            if hasattr(s, "x"):
+                cnt[i] = s.x.size; X[i, :cnt[i]] = s.x; Z[i, :cnt[i]] = s.z
+                lim[i] = (s.left_fp_limit, s.right_fp_limit)
+        out.update(irr_x=X, irr_z=Z, irr_npts=cnt, irr_limits=lim)
+    return out
 
 
 def run_and_capture(solver, tolerance, max_iter=100):
@@ -375,6 +390,94 @@ def case_bc_matrix():
     save("bc_compound_normal", out, base_meta(sol, 1e-6, wall, overbank_fraction=float(over)))
 
 
+def case_irregular():
+    """IrregularSection channels (cross_section.py:207-543) incl. the mixed
+    interpolation path (:932-968).  Three runs: single thalweg; a secondary channel behind a levee
+    with composite roughness (sub-channel conveyance path, :372-447); trapezoid -> polyline mix with
+    centre-line curvature."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.rating_curve import RatingCurve
+    from src.hydromodel.cross_section import TrapezoidalSection, IrregularSection
+
+    def probe(sol, out, levels):
+        """Section functions of the reference at a few stages per node (pins the oracle's section
+        restatement independently of the Newton loop)."""
+        xs = sol.channel.xs_at_node
+        rows = []
+        for i, s in enumerate(xs):
+            for hw_rel in levels:
+                hw = s.z_min + hw_rel
+                h = hw_rel
+                Q = 75.0
+                s._last_hw = None; s._last_hw_n = None
+                rows.append([i, h, Q, s.area(hw), s.wetted_perimeter(hw), s.top_width(hw), s.dA_dh(hw),
+                             s.get_equivalent_n(hw), s.conveyance(hw), s.dR_dA(hw), s.dK_dA(hw),
+                             s.friction_slope(h, Q), s.dSf_dA(h, Q), s.dSf_dQ(h, Q),
+                             s.curvature_slope(h, Q), s.dSc_dA(h, Q), s.dSc_dQ(h, Q)])
+        out["probe"] = np.array(rows, dtype=np.float64)
+
+    def run(name, ch, theta, dt, dx, T, hyd, tol=1e-6, levels=(0.3, 0.9, 1.7, 2.35, 3.1, 4.4), **kw):
+        sol = PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx, simulation_time=T)
+        out, wall = run_and_capture(sol, tol)
+        out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+        probe(sol, out, levels)
+        save(name, out, base_meta(sol, tol, wall, **kw))
+
+    # (a) single thalweg, two different polylines (union of stations at the interpolated nodes)
+    L = 6000.0; S0 = 2e-4
+    xu = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); zu = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
+    xd = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zd = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
+    xs_u = IrregularSection(x=xu, z=S0 * L + zu, n=0.03, bed_slope=S0)
+    xs_d = IrregularSection(x=xd, z=zd, n=0.034, bed_slope=S0)
+    Qb = 40.0
+    hyd = Hydrograph(akbari_hydrograph(Qb, 260.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L)
+    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    run("irr_single", ch, 0.65, 300, 500, 3 * 3600, hyd)
+
+    # (b) secondary channel behind a levee + composite roughness; stage rises through the crest
+    L = 5000.0; S0 = 3e-4
+    x = np.array([0, 8, 12, 28, 32, 44, 50, 62, 70, 84.0])
+    z = np.array([7, 3.2, 0.5, 0.0, 0.7, 2.6, 1.1, 1.3, 2.9, 7.0])
+    xs_u = IrregularSection(x=x, z=S0 * L + z, n=0.03, bed_slope=S0)
+    xs_u.set_roughness_para((0.05, 0.03, 0.06, 12.0, 44.0))
+    xs_d = IrregularSection(x=x * 1.1, z=z * 0.95, n=0.032, bed_slope=S0)
+    xs_d.set_roughness_para((0.05, 0.032, 0.055, 13.2, 48.4))
+    rc = RatingCurve(); rc.set(type='power', a=14.0, b=1.9)
+    h_ds = 1.6
+    Q0 = rc.discharge(h_ds)
+    hyd = Hydrograph(akbari_hydrograph(Q0, 6.0 * Q0, 1.5 * 3600.0, 4 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_ds, rating_curve=rc)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='linear')
+    us.initial_depth = 1.7
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    run("irr_levee", ch, 0.7, 300, 500, 4 * 3600, hyd, rc_type='power', rc_a=14.0, rc_b=1.9,
+        ds_initial_depth=h_ds, us_initial_depth=1.7, levels=(0.4, 1.0, 1.25, 1.8, 2.45, 2.75, 3.3, 4.5))
+
+    # (c) trapezoid -> polyline -> polyline with centre-line coordinates (curvature at the middle section)
+    L = 8000.0; S0 = 2.5e-4
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=30.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    xm = np.array([-40, -25, -16, -6, 5, 17, 26, 41.0]); zm = np.array([6, 2.2, 0.5, 0.0, 0.1, 0.6, 2.4, 6.0])
+    xs_m = IrregularSection(x=xm, z=S0 * L * 0.5 + zm, n=0.031, bed_slope=S0)
+    xd = np.array([-45, -22, -15, -4, 8, 19, 30, 46.0]); zd = np.array([6, 2.0, 0.4, 0.0, 0.2, 0.7, 2.1, 6.0])
+    xs_d = IrregularSection(x=xd, z=zd, n=0.033, bed_slope=S0)
+    Qb = 60.0
+    hyd = Hydrograph(akbari_hydrograph(Qb, 200.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L)
+    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, 0.5 * L, L], [xs_u, xs_m, xs_d])
+    ch.set_coords([[0.0, 0.0], [2500.0, 300.0], [4000.0, 1500.0], [4200.0, 3800.0], [6500.0, 5200.0]],
+                  [0.0, 2500.0, 4400.0, 6700.0, L])
+    run("irr_mixed", ch, 0.65, 300, 500, 3 * 3600, hyd)
+
+
 def _gerd_imports():
     """cwd + read_csv shim for cases/gerd_roseires (harness only)."""
     os.chdir(REF)
@@ -499,6 +602,7 @@ CASES = {
     "synthetic_rect_512": lambda: synthetic_rect("synthetic_rect_512", 2, 512, 4, 20260213),
     "synthetic_trap_64": lambda: synthetic_trap("synthetic_trap_64", 4, 64, 5, 20260214),
     "bc_matrix": case_bc_matrix,
+    "irregular": case_irregular,
 }
 
 if __name__ == "__main__":

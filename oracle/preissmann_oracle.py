@@ -37,6 +37,9 @@ G = 9.80665  # scipy.constants.g, hydraulics.py:2
 
 GEO_KEYS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
             "b_fp_l", "b_fp_r", "m_fp", "curvature")
+# polyline nodes (IrregularSection, cross_section.py:207-543): NaN-padded stations/elevations
+# [N, P], vertex counts [N] (0 = trapezoid-family node) and roughness strip limits [N, 2]
+IRR_KEYS = ("irr_x", "irr_z", "irr_npts", "irr_limits")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -201,6 +204,9 @@ def node_terms(geo, h, Q):
     Returns dict with A, T(=dA_dh), Se, dSe_dA, dSe_dQ where dSe_dA follows the reference's mixed
     convention (channel.py:71-87): friction part per unit AREA, curvature part already multiplied
     by dA/dh (cross_section.py:164)."""
+    if "irr_npts" in geo and np.any(geo["irr_npts"] > 0) and not geo.get("_quiet"):
+        with np.errstate(all="ignore"):                      # trapezoid formulas are meaningless at polyline nodes
+            return node_terms(dict(geo, _quiet=True), h, Q)
     props = section_props(geo, h)
     A, P, R, T, over = props
     K = conveyance(geo, h, props)
@@ -240,11 +246,34 @@ def node_terms(geo, h, Q):
         small = np.abs(curv) <= 1e-12                               # <=1e-12 guard, :156,:168
         dSe_dA = dSf_dA + np.where(small, 0.0, dSc_dA)
         dSe_dQ = dSf_dQ + np.where(small, 0.0, dSc_dQ)
-    return dict(A=A, T=T, Se=Se, dSe_dA=dSe_dA, dSe_dQ=dSe_dQ, K=K, dKdA=dKdA, P=P, R=R, n_eq=n_eq)
+    out = dict(A=A, T=T, Se=Se, dSe_dA=dSe_dA, dSe_dQ=dSe_dQ, K=K, dKdA=dKdA, P=P, R=R, n_eq=n_eq,
+               top_width=T)
+    if "irr_npts" in geo and np.any(geo["irr_npts"] > 0):
+        _splice_irregular(geo, h, Q, out)
+    return out
+
+
+def _splice_irregular(geo, h, Q, out):
+    """Overwrites the entries of polyline nodes with oracle/irregular_oracle.py (scalar per node);
+    for those nodes T is the finite-difference dA/dh the solver uses (solver.py:295-296) and
+    top_width the geometric one."""
+    from . import irregular_oracle as IO
+    out.update({k: np.array(v, dtype=np.float64, copy=True) for k, v in out.items()})
+    for i in np.nonzero(geo["irr_npts"] > 0)[0]:
+        c = int(geo["irr_npts"][i])
+        rough = (geo["n_left"][i], geo["n_main"][i], geo["n_right"][i], *geo["irr_limits"][i])
+        t = IO.node_terms(geo["irr_x"][i, :c], geo["irr_z"][i, :c], rough, float(geo["curvature"][i]),
+                          float(h[i]), float(Q[i]))
+        for k, v in t.items():
+            out[k][i] = v
 
 
 def _one(geo, i):
-    return {k: np.atleast_1d(np.asarray(v, dtype=np.float64)[i]) for k, v in geo.items() if k in GEO_KEYS}
+    i = i % len(geo["z_bed"])
+    g = {k: np.atleast_1d(np.asarray(v, dtype=np.float64)[i]) for k, v in geo.items() if k in GEO_KEYS}
+    if "irr_npts" in geo:
+        g.update({k: np.asarray(geo[k])[i:i + 1] for k in IRR_KEYS})
+    return g
 
 
 # ------------------------------------------------------------------------------------------------
@@ -457,6 +486,8 @@ def problem_from_fixture(fx, meta, member=None):
         a = fx[name]
         return a[member] if member is not None and a.ndim > 1 else a
     geo = {k: np.array(pick("geo_" + k), dtype=np.float64) for k in GEO_KEYS}
+    if "geo_irr_npts" in fx:
+        geo.update({k: np.array(fx["geo_" + k]) for k in IRR_KEYS})
     ic = pick("initial_conditions")
     slope = pick("geo_bed_slope")
 
