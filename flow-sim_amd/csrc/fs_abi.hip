@@ -62,6 +62,10 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
+// polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
+#define FS_ENTRIES_IRREGULAR                                                                      \
+  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 1, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),   \
+  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 4)
 
 #ifdef FS_MINIMAL   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
@@ -71,7 +75,7 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
 #else
-const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32)};
+const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_IRREGULAR};
 #endif
 
 const Entry *pick_kernel(int dtype, int sec, int N, bool light_bc, std::string *why) {
@@ -113,6 +117,8 @@ struct fs_batch {
   // device buffers
   void *hk = nullptr, *Qk = nullptr, *hg = nullptr, *Qg = nullptr;
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
+  void *poly_x = nullptr, *poly_z = nullptr, *poly_lim = nullptr;
+  int32_t *poly_n = nullptr;
   void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
   void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
@@ -167,6 +173,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.hk = (R *)b->hk; a.Qk = (R *)b->Qk; a.hg = (R *)b->hg; a.Qg = (R *)b->Qg;
   a.geo_uniform = (const R *)b->geo_uniform; a.geo_table = (const R *)b->geo_table;
   a.n_override = (const R *)b->n_override;
+  a.poly_x = (const R *)b->poly_x; a.poly_z = (const R *)b->poly_z; a.poly_lim = (const R *)b->poly_lim; a.poly_n = b->poly_n;
   fs::BCDesc<R> *bc[2] = {&a.us, &a.ds};
   for (int s = 0; s < 2; ++s) {
     bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
@@ -198,8 +205,11 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   }
   if (desc->dtype != FS_F64 && desc->dtype != FS_F32) { fail("fs_batch_create: bad dtype"); return nullptr; }
   if (desc->section_mode != FS_SEC_RECT_UNIFORM && desc->section_mode != FS_SEC_TRAP_UNIFORM &&
-      desc->section_mode != FS_SEC_TABLE) {
+      desc->section_mode != FS_SEC_TABLE && desc->section_mode != FS_SEC_IRREGULAR) {
     fail("fs_batch_create: bad section_mode"); return nullptr;
+  }
+  if (desc->section_mode == FS_SEC_IRREGULAR && desc->dtype != FS_F64) {
+    fail("fs_batch_create: FS_SEC_IRREGULAR is fp64 only"); return nullptr;
   }
   if (fs_device_count() <= desc->device || desc->device < 0) {
     fail("fs_batch_create: no HIP device " + std::to_string(desc->device) +
@@ -258,7 +268,7 @@ void fs_batch_destroy(fs_batch *b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
-                  b->iters, b->status};
+                  b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n};
   for (void *p : bufs) if (p) hipFree(p);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
@@ -293,6 +303,50 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
   if (!b || !table) return fail("fs_batch_set_geometry_table: null argument");
   if (b->d.section_mode != FS_SEC_TABLE) return fail("fs_batch_set_geometry_table: batch was created with another section_mode");
   if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * b->d.n_nodes)) return -1;
+  if (n_main_override) {
+    if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
+  } else if (b->n_override) {
+    hipFree(b->n_override); b->n_override = nullptr;
+  }
+  b->have_geo = true;
+  return 0;
+}
+
+int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int32_t *n_pts, int32_t max_pts,
+                                    const double *x, const double *z, const double *limits,
+                                    const double *n_main_override) {
+  if (!b || !table || !n_pts || !x || !z || !limits) return fail("fs_batch_set_geometry_irregular: null argument");
+  if (b->d.section_mode != FS_SEC_IRREGULAR) return fail("fs_batch_set_geometry_irregular: batch was created with another section_mode");
+  if (max_pts < 2) return fail("fs_batch_set_geometry_irregular: max_pts must be >= 2");
+  const size_t N = b->d.n_nodes, P = max_pts;
+  // vertex-major copies [P][N]; unused slots repeat the last vertex so that no lane ever reads NaN
+  std::vector<double> xt(P * N, 0.0), zt(P * N, 0.0), lim(2 * N, 0.0);
+  for (size_t i = 0; i < N; ++i) {
+    const int c = n_pts[i];
+    if (c == 0) continue;
+    if (c < 2 || c > max_pts) return fail("fs_batch_set_geometry_irregular: n_pts must be 0 or 2..max_pts");
+    double zmin = z[i * P];
+    for (int j = 0; j < c; ++j) {
+      const double xv = x[i * P + j], zv = z[i * P + j];
+      if (!(xv == xv) || !(zv == zv)) return fail("x and z must have the same shape");            // cross_section.py:222 (NaN padding inside the count)
+      if (j && xv < x[i * P + j - 1]) return fail("fs_batch_set_geometry_irregular: x must be ascending (IrregularSection sorts it, cross_section.py:231)");
+      zmin = zv < zmin ? zv : zmin;
+    }
+    if (table[(size_t)FS_GEO_Z_BED * N + i] != zmin)
+      return fail("fs_batch_set_geometry_irregular: table row Z_BED must hold min(z) of a polyline node (IrregularSection.z_min)");
+    for (size_t j = 0; j < P; ++j) {
+      const size_t src = i * P + (j < (size_t)c ? j : (size_t)c - 1);
+      xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
+    }
+    lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
+  }
+  if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * N)) return -1;
+  if (b->poly_x) { hipFree(b->poly_x); b->poly_x = nullptr; }
+  if (b->poly_z) { hipFree(b->poly_z); b->poly_z = nullptr; }
+  if (upload(b, &b->poly_x, xt.data(), P * N) || upload(b, &b->poly_z, zt.data(), P * N) ||
+      upload(b, &b->poly_lim, lim.data(), 2 * N)) return -1;
+  if (!b->poly_n) HIP_TRY(hipMalloc((void **)&b->poly_n, N * 4));
+  HIP_TRY(hipMemcpy(b->poly_n, n_pts, N * 4, hipMemcpyHostToDevice));
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
   } else if (b->n_override) {
@@ -488,12 +542,14 @@ int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double
     if (b->d.dtype == FS_F64) {
       fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
                                (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
+                               (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
                                (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
                                (double *)dev[5], (double *)dev[6], (double *)dev[7]};
       hipLaunchKernelGGL((fs::derive_fields_kernel<double>), grid, dim3(256), 0, b->stream, a);
     } else {
       fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
                               (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
+                              (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
                               (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
                               (float *)dev[5], (float *)dev[6], (float *)dev[7]};
       hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);

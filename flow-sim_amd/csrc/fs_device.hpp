@@ -256,6 +256,39 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
 template <typename R>
 __device__ __noinline__ GeneralProps<R> general_props_call(const SecParams<R> s, R h) { return general_props(s, h); }
 
+// Curvature slope Sc and its derivatives (cross_section.py:145-175 over hydraulics.py:94-153) added to
+// (Se, dSe/dA, dSe/dQ).  T = geometric top width, dAdh = what the section reports as dA/dh (the same
+// number for the trapezoid family, a finite difference for polylines), y13 = Rh^(-1/3).
+template <typename R>
+__device__ __forceinline__ void add_curvature(R curv, R A, R T, R dAdh, R neq, R y13, R dRdA, R h, R Q, R &Se,
+                                              R &dSeA, R &eQ) {
+  if (curv == R(0)) return;               // ==0 guard for Sc, <=1e-12 guard for its derivatives
+  const R rc = R(1) / curv;
+  const R V = Q / fmax_(A, R(1e-6));                            // hydraulics.py:155-168
+  const R D = A / fmax_(T, R(1e-6));
+  const R Fr = V / sqrt_(R(kG) * fmax_(D, R(1e-6)));
+  const R f = R(8) * R(kG) * neq * neq * y13;                   // 8 g / C^2 with C = R^(1/6)/n, :217-229
+  const R sq = sqrt_(f);
+  const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
+  const R den = (R(0.565) + sq) * rc * rc;
+  Se += num / den;                                              // :94-117
+  if (fabs_(curv) > R(1e-12)) {
+    const R gD = R(kG) * (A / T);
+    const R Vr = Q / A;
+    const R rs = R(1) / sqrt_(gD), rs3 = rs * rs * rs;          // (gD)^-0.5, (gD)^-1.5
+    const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * (R(1) / T) + (-Q / (A * A)) * rs;
+    const R y2 = y13 * y13;
+    const R dfA = -(R(8.0 / 3.0)) * R(kG) * neq * neq * (y2 * y2) * dRdA;
+    const R dnum = (R(2.86) / (R(2) * sq) * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
+                   (R(2.86) * sq + R(2.07) * f) * (R(2) * h * (R(1) / T) * Fr * Fr + h * h * R(2) * Fr * dFrA);
+    const R dden = (R(1) / (R(2) * sq) * dfA) * rc * rc;
+    dSeA += (dnum * den - num * dden) / (den * den) * dAdh;     // :119-137, x dA_dh (cross_section.py:164)
+    const R dFrQ = (R(1) / A) * rs;
+    const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
+    eQ += (dnumq * den) / (den * den);                          // :139-153
+  }
+}
+
 template <typename R>
 __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
   const GeneralProps<R> g = general_props(s, h);
@@ -265,33 +298,7 @@ __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h
   const R Sf = Q * aQ * iK2;
   R dSeA = R(-2) * Sf * (g.dKdA / g.K);   // per unit area
   R Se = Sf, eQ = R(2) * aQ * iK2;
-  if (s.curv != R(0)) {                   // ==0 guard for Sc, <=1e-12 guard for its derivatives
-    const R A = g.A, T = g.T, Rh = g.Rh;
-    const R rc = R(1) / s.curv;
-    const R V = Q / fmax_(A, R(1e-6));                            // hydraulics.py:155-168
-    const R D = A / fmax_(T, R(1e-6));
-    const R Fr = V / sqrt_(R(kG) * fmax_(D, R(1e-6)));
-    const R f = R(8) * R(kG) * g.neq * g.neq * g.y13;             // 8 g / C^2 with C = R^(1/6)/n, :217-229
-    const R sq = sqrt_(f);
-    const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
-    const R den = (R(0.565) + sq) * rc * rc;
-    Se = Sf + num / den;                                          // :94-117
-    if (fabs_(s.curv) > R(1e-12)) {
-      const R gD = R(kG) * (A / T);
-      const R Vr = Q / A;
-      const R rs = R(1) / sqrt_(gD), rs3 = rs * rs * rs;          // (gD)^-0.5, (gD)^-1.5
-      const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * (R(1) / T) + (-Q / (A * A)) * rs;
-      const R y2 = g.y13 * g.y13;
-      const R dfA = -(R(8.0 / 3.0)) * R(kG) * g.neq * g.neq * (y2 * y2) * g.dRdA;
-      const R dnum = (R(2.86) / (R(2) * sq) * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
-                     (R(2.86) * sq + R(2.07) * f) * (R(2) * h * (R(1) / T) * Fr * Fr + h * h * R(2) * Fr * dFrA);
-      const R dden = (R(1) / (R(2) * sq) * dfA) * rc * rc;
-      dSeA += (dnum * den - num * dden) / (den * den) * T;        // :119-137, x dA_dh (cross_section.py:164)
-      const R dFrQ = (R(1) / A) * rs;
-      const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
-      eQ += (dnumq * den) / (den * den);                          // :139-153
-    }
-  }
+  add_curvature(s.curv, g.A, g.T, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
   t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q / g.A;
   return t;
 }

@@ -24,6 +24,7 @@
 #pragma once
 #include <type_traits>
 #include "fs_device.hpp"
+#include "fs_poly.hpp"
 
 // build-time experiment switches (defaults = the configuration that measured fastest)
 #ifndef FS_SKEW
@@ -68,6 +69,9 @@ template <typename R> struct KernelArgs {
   const R *geo_uniform;    // RECT_UNIFORM: [FS_RU_NPARAM][B]
   const R *geo_table;      // TABLE: [FS_GEO_NPARAM][N]
   const R *n_override;     // TABLE: [B] or nullptr
+  const R *poly_x, *poly_z;      // IRREGULAR: [P][N] polyline stations / elevations (vertex-major)
+  const R *poly_lim;             // IRREGULAR: [2][N] roughness strip limits
+  const int32_t *poly_n;         // IRREGULAR: [N] vertex counts (0 = trapezoid-family node of the table)
   BCDesc<R> us, ds;
   R *Yprev;                // [B] storage stage of the current level
   R *stage_hist;           // [levels][B] storage stage per level (boundary.py:126-131)
@@ -182,6 +186,47 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   template <bool BCFAST>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+  }
+};
+
+// TABLE plus polyline nodes (IrregularSection): per node either a row of the trapezoid table or a
+// polyline; both evaluations stay out of line (fs_poly.hpp walks the vertices in loops).
+template <typename R>
+__device__ __noinline__ NodeTerms<R> node_terms_general_call(const SecParams<R> s, R h, R Q) { return node_terms_general(s, h, Q); }
+
+template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
+  static constexpr bool kConstT = false;
+  Geometry<R, FS_SEC_TABLE> tb;
+  const R *px, *pz, *plim;
+  const int32_t *pn;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+    tb.init(a, reach);
+    px = a.poly_x; pz = a.poly_z; plim = a.poly_lim; pn = a.poly_n;
+  }
+  __device__ __forceinline__ R terms_T() const { return R(0); }
+  __device__ __forceinline__ R bed_step(int node) const { return tb.bed_step(node); }
+  __device__ __forceinline__ R bed(int node) const { return tb.bed(node); }
+  __device__ __forceinline__ SecParams<R> section(int node) const { return tb.section(node); }
+  __device__ __forceinline__ PolyNode<R> poly(int node) const {
+    PolyNode<R> p;
+    const int N = tb.N;
+    auto g = [&](int row) { return tb.tab[(size_t)row * N + node]; };
+    p.x = px + node; p.z = pz + node; p.stride = N; p.n = pn[node];
+    p.nl = g(FS_GEO_N_LEFT); p.nm = tb.has_over ? tb.n_over : g(FS_GEO_N_MAIN); p.nr = g(FS_GEO_N_RIGHT);
+    p.liml = plim[node]; p.limr = plim[N + node];
+    p.curv = g(FS_GEO_CURVATURE); p.zmin = g(FS_GEO_Z_BED);
+    return p;
+  }
+  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
+    if (pn[node] > 0) return node_terms_poly(poly(node), h, Q);
+    return node_terms_general_call(section(node), h, Q);
+  }
+  template <bool BCFAST>
+  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
+                                               R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    if (pn[node] > 0 && bc.kind == FS_BC_NORMAL_DEPTH)
+      return bc_normal_depth_poly(poly(node), bc_param(bc, 0, reach, B), bc_param(bc, 1, reach, B), h, Q);
     return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
@@ -683,6 +728,8 @@ template <typename R> struct DeriveArgs {
   int32_t B, N, first, n, section_mode;
   const R *hist_h, *hist_Q;       // [levels][B][N]
   const R *geo_uniform, *geo_table;
+  const R *poly_x, *poly_z;       // IRREGULAR (see KernelArgs)
+  const int32_t *poly_n;
   R *level, *area, *top, *froude, *vel, *cel, *amp, *peak;   // [n][B][N] (peak: [B][N]) or nullptr
 };
 
@@ -692,11 +739,16 @@ template <typename R> __global__ void derive_fields_kernel(const DeriveArgs<R> a
   if (i >= BN) return;
   const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
   SecParams<R> s;
-  if (a.section_mode == FS_SEC_TABLE) {
+  PolyNode<R> pnode;
+  pnode.n = 0;
+  if (a.section_mode == FS_SEC_TABLE || a.section_mode == FS_SEC_IRREGULAR) {
     auto g = [&](int row) { return a.geo_table[(size_t)row * a.N + node]; };
     s.z = g(FS_GEO_Z_BED); s.b = g(FS_GEO_B_MAIN); s.m = g(FS_GEO_M_MAIN);
     s.compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
     s.hbf = g(FS_GEO_H_BANKFULL); s.bl = g(FS_GEO_B_FP_LEFT); s.br = g(FS_GEO_B_FP_RIGHT); s.mfp = g(FS_GEO_M_FP);
+    if (a.section_mode == FS_SEC_IRREGULAR && a.poly_n[node] > 0) {
+      pnode.x = a.poly_x + node; pnode.z = a.poly_z + node; pnode.stride = a.N; pnode.n = a.poly_n[node];
+    }
   } else {
     const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
     const R w2 = R(node) / R(a.N - 1);
@@ -720,6 +772,7 @@ template <typename R> __global__ void derive_fields_kernel(const DeriveArgs<R> a
       T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
     }
     if (d <= R(0)) { A = R(0); T = R(0); }
+    if (pnode.n > 0) poly_area_top(pnode, h + s.z, A, T);     // cross_section.py:248-328
     const R V = Q / A;
     if (a.level) a.level[dst] = h + s.z;
     if (a.area) a.area[dst] = A;

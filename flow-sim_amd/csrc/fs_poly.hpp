@@ -1,0 +1,204 @@
+// fs_poly.hpp - polyline ("irregular") cross-sections on the device, fp64.
+//
+// What the reference's IrregularSection does per call (src/hydromodel/cross_section.py:207-543):
+// wetted area / perimeter / top width by walking the polyline, composite roughness over left / main
+// / right strips, central differences with dh = 1e-6 for dR/dA and dA/dh, and - when the water
+// surface splits the section into two or more wetted runs of >= 2 vertices - the conveyance sum over
+// temporary sub-sections.  Here one pass over the vertices accumulates, edge by edge, everything a
+// (sub-)section evaluation needs: (A, P) at the three stages hw, hw -+ dh, the top width at hw and
+// the (A, P) of the three roughness strips at hw.
+//
+// Reference behaviour that is kept (tests/golden/irr_*.npz pin it):
+//   * a vertex exactly on the water surface is neither wet nor above: its edge contributes nothing
+//     (:262, :292, :300);
+//   * the left water's-edge point of a temporary sub-section sits at the x of the first wet vertex
+//     (np.interp over a decreasing abscissa, :357); the right one is interpolated (:361);
+//   * evaluated at its own creation stage a sub-section loses the edge triangles, at +dh it has
+//     them: that is what its finite-difference dR/dA sees (:523-531).
+#pragma once
+#include "fs_device.hpp"
+
+namespace fs {
+
+// vertex j of a node lives at x[j * stride], z[j * stride] (vertex-major [P][N] tables: the lanes
+// of a wave walk different nodes in step)
+template <typename R> struct PolyNode {
+  const R *x, *z;
+  int stride, n;
+  R nl, nm, nr, liml, limr, curv, zmin;
+};
+
+// vertices [lo, hi] of a node, optionally extended by a water's-edge point at elevation zc on
+// either side (the x_seg / z_seg of cross_section.py:352-365)
+template <typename R> struct PolyView { int lo, hi; bool vl, vr; R xl, xr, zc; };
+
+template <typename R> struct PolyEval { R A, P, Rh, T, neq, K, dRdA, dKdA, dAdh, y13; };
+
+// contribution of the edge (x0,z0)-(x1,z1) below stage hw; cross_section.py:286-322 edge by edge
+template <typename R>
+__device__ __forceinline__ void poly_edge(R x0, R z0, R x1, R z1, R hw, R &A, R &P, R &T) {
+  const R d0 = hw - z0, d1 = hw - z1;
+  const bool w0 = d0 > R(0), w1 = d1 > R(0);
+  if (w0 && w1) {
+    const R dx = x1 - x0, dz = z1 - z0;
+    A += R(0.5) * (d0 + d1) * dx;
+    P += sqrt_(dx * dx + dz * dz);
+    T += dx;
+  } else if (w1 && z0 > hw) {                 // left water's edge, :289-296
+    const R t = (hw - z0) / (z1 - z0);
+    const R xl = x0 + t * (x1 - x0);
+    const R dx = x1 - xl, dz = z1 - hw;
+    A += R(0.5) * d1 * dx;
+    P += sqrt_(dx * dx + dz * dz);
+    T += dx;
+  } else if (w0 && z1 > hw) {                 // right water's edge, :298-305
+    const R t = (hw - z0) / (z1 - z0);
+    const R xr = x0 + t * (x1 - x0);
+    const R dx = xr - x0, dz = hw - z0;
+    A += R(0.5) * d0 * dx;
+    P += sqrt_(dx * dx + dz * dz);
+    T += dx;
+  }
+}
+
+template <typename R> __device__ __forceinline__ R strip_K(R A, R P, R n) {   // :457-481
+  return (A <= R(0) || P <= R(0)) ? R(0) : conv_(A, n, A / P);
+}
+
+// properties / get_equivalent_n / conveyance / dR_dA / dK_dA / dA_dh of one (sub-)section at stage hw
+template <typename R>
+__device__ __noinline__ PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyView<R> v, R hw) {
+  const R dh = R(1e-6);
+  const int j0 = v.lo - (v.vl ? 1 : 0), j1 = v.hi + (v.vr ? 1 : 0);
+  auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : nd.x[(size_t)j * nd.stride]); };
+  auto Z = [&](int j) { return (j < v.lo || j > v.hi) ? v.zc : nd.z[(size_t)j * nd.stride]; };
+  const R xa = X(j0), xb = X(j1);             // self.x[0], self.x[-1] of this (sub-)section
+  R A0 = 0, P0 = 0, T0 = 0, A1 = 0, P1 = 0, A2 = 0, P2 = 0, Td = 0;
+  R Al = 0, Pl = 0, Am = 0, Pm = 0, Ar = 0, Pr = 0;
+  R x0 = xa, z0 = Z(j0);
+  for (int j = j0; j < j1; ++j) {
+    const R x1 = X(j + 1), z1 = Z(j + 1);
+    R eA = 0, eP = 0, eT = 0;
+    poly_edge(x0, z0, x1, z1, hw, eA, eP, eT);
+    A0 += eA; P0 += eP; T0 += eT;
+    poly_edge(x0, z0, x1, z1, hw - dh, A1, P1, Td);
+    poly_edge(x0, z0, x1, z1, hw + dh, A2, P2, Td);
+    // roughness strips: an edge belongs to a strip when both of its stations pass the strip's mask (:459)
+    if (x0 >= xa && x1 <= nd.liml) { Al += eA; Pl += eP; }
+    if (x0 >= nd.liml && x1 <= nd.limr) { Am += eA; Pm += eP; }
+    if (x0 >= nd.limr && x1 <= xb) { Ar += eA; Pr += eP; }
+    x0 = x1; z0 = z1;
+  }
+  PolyEval<R> e;
+  e.A = A0; e.P = P0; e.T = T0;
+  e.Rh = P0 > R(0) ? A0 / P0 : R(0);
+  e.y13 = e.Rh > R(0) ? rcbrt_pos(e.Rh) : R(0);
+  const R R23 = e.Rh * e.y13;
+  e.neq = nd.nm;                                                        // :486-487 fallback
+  if (A0 > R(0) && P0 > R(0)) {
+    const R Kt = p23_(p32_(strip_K(Al, Pl, nd.nl)) + p32_(strip_K(Am, Pm, nd.nm)) + p32_(strip_K(Ar, Pr, nd.nr)));
+    if (Kt > R(0)) e.neq = A0 * R23 / Kt;                               // :492-498
+  }
+  e.K = A0 <= R(0) ? R(0) : A0 * R23 / e.neq;                           // :505-513
+  const R R1 = P1 > R(0) ? A1 / P1 : R(0), R2 = P2 > R(0) ? A2 / P2 : R(0);
+  e.dRdA = (A2 - A1) == R(0) ? R(0) : (R2 - R1) / (A2 - A1);            // :523-531
+  e.dKdA = A0 <= R(0) ? R(0) : (R23 + A0 * R(2.0 / 3.0) * e.y13 * e.dRdA) / e.neq;   // :515-521
+  e.dAdh = (A2 - A1) / (R(2) * dh);                                     // :533-538
+  return e;
+}
+
+template <typename R> __device__ __forceinline__ PolyView<R> poly_whole(const PolyNode<R> &nd) {
+  PolyView<R> v;
+  v.lo = 0; v.hi = nd.n - 1; v.vl = false; v.vr = false; v.xl = R(0); v.xr = R(0); v.zc = R(0);
+  return v;
+}
+
+// Se, dSe/dA, dSe/dQ, A, dA/dh of a polyline node: friction_slope / dSf_dA / dSf_dQ of
+// cross_section.py:372-447 (sub-channel sum when >= 2 wetted runs) plus the base-class curvature terms.
+template <typename R>
+__device__ __noinline__ NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
+  const R hw = h + nd.zmin;
+  const PolyEval<R> e = poly_eval(nd, poly_whole(nd), hw);
+  R K = e.K, dK = e.dKdA;
+  // wetted runs of >= 2 vertices (get_subchannels, :330-370)
+  int nsub = 0;
+  {
+    int run = 0;
+    for (int j = 0; j < nd.n; ++j) {
+      const bool wet = nd.z[(size_t)j * nd.stride] < hw;
+      if (wet) ++run;
+      if (!wet || j == nd.n - 1) { nsub += run >= 2; run = 0; }
+    }
+  }
+  if (nsub >= 2) {
+    R Ks = 0, dKs = 0;
+    int s = -1;
+    for (int j = 0; j <= nd.n; ++j) {
+      const bool wet = j < nd.n && nd.z[(size_t)j * nd.stride] < hw;
+      if (wet && s < 0) s = j;
+      if (!wet && s >= 0) {
+        const int en = j;                                   // one past the last wet vertex
+        if (en - s >= 2) {
+          PolyView<R> v;
+          v.lo = s; v.hi = en - 1; v.zc = hw;
+          v.vl = s > 0 && nd.z[(size_t)(s - 1) * nd.stride] > hw;
+          v.xl = nd.x[(size_t)s * nd.stride];               // :357 (np.interp, decreasing abscissa)
+          v.vr = false; v.xr = R(0);
+          if (en < nd.n) {
+            const R za = nd.z[(size_t)(en - 1) * nd.stride], zb = nd.z[(size_t)en * nd.stride];
+            if (za < hw && zb > hw) {                       // :360-363
+              const R xa_ = nd.x[(size_t)(en - 1) * nd.stride], xb_ = nd.x[(size_t)en * nd.stride];
+              v.vr = true;
+              v.xr = (xb_ - xa_) / (zb - za) * (hw - za) + xa_;
+            }
+          }
+          const PolyEval<R> sub = poly_eval(nd, v, hw);
+          Ks += p32_(sub.K);                                // :389-390
+          dKs += R(1.5) * sqrt_(sub.K) * sub.dKdA;          // :412-413
+        }
+        s = -1;
+      }
+    }
+    K = p23_(Ks);                                           // :392, :415
+    dK = R(2.0 / 3.0) * rcbrt_pos(Ks) * dKs;                // :416
+  }
+  NodeTerms<R> t;
+  const R iK2 = R(1) / (K * K);
+  const R aQ = fabs_(Q);
+  const R Sf = Q * aQ * iK2;
+  R dSeA = R(-2) * Sf * (dK / K);
+  R Se = Sf, eQ = R(2) * aQ * iK2;
+  add_curvature(nd.curv, e.A, e.T, e.dAdh, e.neq, e.y13, e.dRdA, h, Q, Se, dSeA, eQ);
+  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eA = dSeA * e.dAdh; t.eQ = eQ; t.v = Q / e.A;
+  return t;
+}
+
+// normal-depth boundary row at a polyline node: conveyance at hw = z_min + h for the residual,
+// dK/dA * dA/dh at hw = h + bed_level for the derivative (boundary.py:80, :91, :161, :180)
+template <typename R>
+__device__ __noinline__ BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0, R bed, R h, R Q) {
+  const R sg = S0 < R(0) ? R(-1) : R(1);
+  const R rt = sqrt_(fabs_(S0));
+  const PolyEval<R> gr = poly_eval(nd, poly_whole(nd), nd.zmin + h);
+  const PolyEval<R> gd = poly_eval(nd, poly_whole(nd), h + bed);
+  BCRow<R> r;
+  r.res = Q - sg * gr.K * rt;
+  r.dh = R(0) - sg * gd.dKdA * rt * gd.dAdh;
+  r.dq = R(1);
+  return r;
+}
+
+// area and geometric top width only (Solver.prepare_results, solver.py:65-127)
+template <typename R>
+__device__ __forceinline__ void poly_area_top(const PolyNode<R> &nd, R hw, R &A, R &T) {
+  R P = 0;
+  A = 0; T = 0;
+  R x0 = nd.x[0], z0 = nd.z[0];
+  for (int j = 1; j < nd.n; ++j) {
+    const R x1 = nd.x[(size_t)j * nd.stride], z1 = nd.z[(size_t)j * nd.stride];
+    poly_edge(x0, z0, x1, z1, hw, A, P, T);
+    x0 = x1; z0 = z1;
+  }
+}
+
+}  // namespace fs

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "..", "csrc", "libflowsim_hip.so")
 
 F64, F32 = 0, 1
-SEC_RECT_UNIFORM, SEC_TRAP_UNIFORM, SEC_TABLE = 0, 1, 2
+SEC_RECT_UNIFORM, SEC_TRAP_UNIFORM, SEC_TABLE, SEC_IRREGULAR = 0, 1, 2, 3
 RU_WIDTH, RU_MANNING, RU_Z_US, RU_Z_DS, RU_NPARAM = 0, 1, 2, 3, 4
 TU_SIDE_SLOPE, TU_NPARAM = 4, 5
 GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
@@ -46,6 +46,7 @@ SIGNATURES = {
     "fs_batch_set_scheme": (C.c_int, [_P, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32]),
     "fs_batch_set_geometry_uniform": (C.c_int, [_P, _D]),
     "fs_batch_set_geometry_table": (C.c_int, [_P, _D, _D]),
+    "fs_batch_set_geometry_irregular": (C.c_int, [_P, _D, _I, C.c_int32, _D, _D, _D, _D]),
     "fs_batch_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, _D, C.c_int32, C.c_int32, _D]),
     "fs_batch_set_state": (C.c_int, [_P, _D, _D]),
     "fs_batch_set_state_uniform": (C.c_int, [_P, _D, _D]),

@@ -46,7 +46,7 @@ class PreissmannBatch:
         self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
         self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
         self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "trap_uniform": A.SEC_TRAP_UNIFORM,
-                     "table": A.SEC_TABLE}[section_mode]
+                     "table": A.SEC_TABLE, "irregular": A.SEC_IRREGULAR}[section_mode]
         self._lib = A.lib()
         desc = A.BatchDesc(self.B, self.N, self.dtype, self.mode, device, self.L,
                            (A.FLAG_HISTORY if history else 0) | (A.FLAG_TRACE if trace else 0), 0)
@@ -96,6 +96,25 @@ class PreissmannBatch:
             assert ov.shape == (self.B,)
         A.check(self._lib.fs_batch_set_geometry_table(self._h, _dptr(tab), _dptr(ov) if ov is not None else None),
                 "set_geometry_table")
+
+    def set_geometry_irregular(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):
+        """geo: the TABLE rows plus irr_x / irr_z [N, P] (rows padded beyond irr_npts), irr_npts [N]
+        (0 = trapezoid-family node) and irr_limits [N, 2] (IrregularSection.left/right_fp_limit)."""
+        tab = np.empty((A.GEO_NPARAM, self.N), dtype=np.float64)
+        for i, k in enumerate(A.GEO_ROWS):
+            tab[i] = np.asarray(geo[k], dtype=np.float64)
+        cnt = np.ascontiguousarray(geo["irr_npts"], dtype=np.int32)
+        x = np.ascontiguousarray(geo["irr_x"], dtype=np.float64)
+        z = np.ascontiguousarray(geo["irr_z"], dtype=np.float64)
+        lim = np.ascontiguousarray(geo["irr_limits"], dtype=np.float64)
+        assert cnt.shape == (self.N,) and x.shape == z.shape and x.shape[0] == self.N and lim.shape == (self.N, 2)
+        ov = None
+        if n_main_override is not None:
+            ov = np.ascontiguousarray(n_main_override, dtype=np.float64)
+            assert ov.shape == (self.B,)
+        A.check(self._lib.fs_batch_set_geometry_irregular(
+            self._h, _dptr(tab), cnt.ctypes.data_as(A._I), x.shape[1], _dptr(x), _dptr(z), _dptr(lim),
+            _dptr(ov) if ov is not None else None), "set_geometry_irregular")
 
     def set_boundary(self, side: int, spec: BoundarySpec):
         names = _KIND_PARAMS[spec.kind]

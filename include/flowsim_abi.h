@@ -46,8 +46,12 @@ enum { FS_F64 = 0, FS_F32 = 1 };
  *   TABLE        : one [FS_GEO_NPARAM][N] table of TrapezoidalSection parameters at the nodes
  *                  (cross_section.py:569-613 after interpolation, channel.py:213-241), shared by
  *                  all reaches, optional per-reach main-channel Manning n
- *                  (cases/gerd_roseires/custom_functions.py:147). */
-enum { FS_SEC_RECT_UNIFORM = 0, FS_SEC_TRAP_UNIFORM = 1, FS_SEC_TABLE = 2 };
+ *                  (cases/gerd_roseires/custom_functions.py:147).
+ *   IRREGULAR    : TABLE plus polyline nodes: what Channel.xs_at_node holds when any input
+ *                  section is an IrregularSection (cross_section.py:207-543; mixed interpolation
+ *                  :932-968).  fp64 only (the reference's 1e-6 finite differences do not survive
+ *                  single precision). */
+enum { FS_SEC_RECT_UNIFORM = 0, FS_SEC_TRAP_UNIFORM = 1, FS_SEC_TABLE = 2, FS_SEC_IRREGULAR = 3 };
 
 /* rows of the RECT_UNIFORM parameter block, each [B] */
 enum { FS_RU_WIDTH = 0, FS_RU_MANNING = 1, FS_RU_Z_US = 2, FS_RU_Z_DS = 3, FS_RU_NPARAM = 4 };
@@ -115,6 +119,15 @@ int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double 
 int fs_batch_set_geometry_uniform(fs_batch *b, const double *params);
 /* TABLE: table[FS_GEO_NPARAM][N]; n_main_override[B] or NULL */
 int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *n_main_override);
+/* IRREGULAR: table[FS_GEO_NPARAM][N] as for TABLE.  Node i with n_pts[i] > 0 is the polyline
+ * x[i][0..n_pts[i]), z[i][..] (rows of length max_pts, x ascending, >= 2 points; IrregularSection.x/.z
+ * after its argsort, cross_section.py:231-233) with roughness strips split at limits[i][0..1]
+ * (left_fp_limit, right_fp_limit, +-inf allowed; cross_section.py:105-111); of its table column only
+ * Z_BED (= min z), N_MAIN, N_LEFT, N_RIGHT and CURVATURE are read.  n_pts[i] == 0: trapezoid-family
+ * node described by the table column.  n_main_override[B] or NULL. */
+int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int32_t *n_pts, int32_t max_pts,
+                                    const double *x, const double *z, const double *limits,
+                                    const double *n_main_override);
 
 /* one boundary (Boundary.__init__, boundary.py:10-46).  params[n_params] when per_reach == 0,
  * params[n_params][B] otherwise.  target[max_levels][B] (value at t = level*dt, i.e.

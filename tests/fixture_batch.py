@@ -60,7 +60,9 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     B = len(problems)
     if mode == "auto":
         mode = "rect_uniform" if all(is_rect_uniform(p) for p in problems) else "table"
-        if mode == "table" and B > 1:
+        if "irr_npts" in p0.geo and np.any(p0.geo["irr_npts"] > 0):
+            mode = "irregular"
+        if mode != "rect_uniform" and B > 1:
             assert all(all(np.array_equal(p.geo[k], p0.geo[k]) for k in O.GEO_KEYS) for p in problems), \
                 "TABLE geometry is shared by the batch: reaches with their own channel need their own batch"
     b = PreissmannBatch(B, p0.N, p0.nt, dtype=dtype, section_mode=mode, history=history)
@@ -68,6 +70,8 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     if mode == "rect_uniform":
         b.set_geometry_uniform([p.geo["b_main"][0] for p in problems], [p.geo["n_main"][0] for p in problems],
                                [p.geo["z_bed"][0] for p in problems], [p.geo["z_bed"][-1] for p in problems])
+    elif mode == "irregular":
+        b.set_geometry_irregular(p0.geo, n_main_override)
     else:
         b.set_geometry_table(p0.geo, n_main_override)
     b.set_boundary(A.UPSTREAM, merge_specs([boundary_spec(p.us, p.nt) for p in problems], B))

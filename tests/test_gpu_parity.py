@@ -38,6 +38,8 @@ def run_and_compare(path, mode, shape=None, monkeypatch=None):
     from fixture_batch import batch_from_problems
     fx, meta, probs = problems_of(path)
     B = meta.get("B")
+    if "geo_irr_npts" in fx.files and mode == "table":
+        mode = "irregular"                     # polyline nodes: the TABLE mode cannot express them
     if shape:
         monkeypatch.setenv("FS_KERNEL_SHAPE", shape)
     override = None
@@ -99,6 +101,42 @@ def test_table_mode_kernel_shapes(shape, monkeypatch):
         if 64 * m * w < meta["N"] - 1:
             continue
         run_and_compare(path, "table", shape, monkeypatch)
+
+
+@pytest.mark.parametrize("shape", ["1,1", "2,1", "8,1", "8,4"])
+def test_irregular_mode_kernel_shapes(shape, monkeypatch):
+    """Polyline sections (IrregularSection): single thalweg, levee with sub-channel conveyance and
+    composite roughness, trapezoid/polyline mix with curvature - in every kernel shape."""
+    for name in ("irr_single", "irr_levee", "irr_mixed"):
+        run_and_compare(os.path.join(GOLDEN, name + ".npz"), "irregular", shape, monkeypatch)
+
+
+@pytest.mark.parametrize("name", ["irr_single", "irr_levee", "irr_mixed"])
+def test_irregular_derived_fields(name):
+    """fs_batch_derive on polyline nodes against the reference's Solver.prepare_results output."""
+    from fixture_batch import batch_from_problems
+    fx, meta, probs = problems_of(os.path.join(GOLDEN, name + ".npz"))
+    with batch_from_problems(probs) as b:
+        b.step(probs[0].nt - 1)
+        d = b.derive(0, probs[0].nt)
+    for f in ("area", "top_width", "froude_number", "velocity", "wave_celerity", "level"):
+        assert rel_err(d[f][:, 0], fx["derived_" + f], 1e-6) <= TOL, f
+
+
+def test_irregular_mode_rejects_bad_input():
+    from flowsim_amd import PreissmannBatch
+    from flowsim_amd._abi import FlowsimError
+    with pytest.raises(FlowsimError, match="fp64 only"):
+        PreissmannBatch(1, 8, 4, dtype="f32", section_mode="irregular")
+    fx, meta, probs = problems_of(os.path.join(GOLDEN, "irr_single.npz"))
+    geo = dict(probs[0].geo)
+    with PreissmannBatch(1, probs[0].N, 4, section_mode="irregular") as b:
+        bad = dict(geo); bad["irr_x"] = geo["irr_x"][:, ::-1].copy()
+        with pytest.raises(FlowsimError, match="ascending|same shape"):
+            b.set_geometry_irregular(bad)
+        bad = dict(geo); bad["z_bed"] = geo["z_bed"] + 0.5
+        with pytest.raises(FlowsimError, match="min\\(z\\)"):
+            b.set_geometry_irregular(bad)
 
 
 def test_oracle_agreement_on_fresh_inputs():

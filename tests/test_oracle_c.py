@@ -10,7 +10,8 @@ from conftest import GOLDEN
 from oracle import c_oracle as CO
 from oracle import preissmann_oracle as O
 
-FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+# the C restatement covers the trapezoid family; polyline channels are pinned by the numpy oracle (test_oracle_irregular.py)
+FIXTURES = [p for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))) if not os.path.basename(p).startswith("irr_")]
 
 
 def rel_err(got, want, floor):
