@@ -1,13 +1,14 @@
 """Cross-sections on the host: the trapezoid family of the reference
-(src/hydromodel/cross_section.py:549-846) and the distance-weighted interpolation between two
-sections (cross_section.py:857-930).
+(src/hydromodel/cross_section.py:549-846), polyline sections (IrregularSection, :207-543) and the
+distance-weighted interpolation between two sections (cross_section.py:857-968).
 
 Geometry is kept as plain parameter records; `section_table()` turns a list of sections into the
 [param][node] structure-of-arrays block the kernel reads (include/flowsim_abi.h, FS_GEO_*), and
 `props()` evaluates area / perimeter / top width / conveyance for whole arrays of nodes at once -
 used for initial conditions and post-processing, never inside the Newton loop.
 
-IrregularSection (polyline sections) is SURVEY.md 8(f) rank 2 and not provided yet.
+Polyline sections are evaluated here only for set-up work (initial conditions, diagnostics); inside
+the Newton loop the kernel walks the same polylines itself (csrc/fs_poly.hpp, FS_SEC_IRREGULAR).
 """
 from abc import ABC, abstractmethod
 
@@ -84,16 +85,51 @@ def equivalent_n(geo, hw, pr=None, K=None):
     return n
 
 
+def area_top(sections, geo, level):
+    """Wetted area and top width at water levels `level` [..., N] for the node sections: the array
+    formulas above for trapezoid nodes, a per-node polyline walk otherwise (diagnostics and the
+    host fallback of the post-processing only)."""
+    level = np.asarray(level, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        A, P, R, T, _ = props({n: v for n, v in geo.items() if n in GEO_ROWS}, level)
+    A, T = np.array(A, dtype=np.float64), np.array(T, dtype=np.float64)
+    for i, s in enumerate(sections):
+        if isinstance(s, IrregularSection):
+            for idx in np.ndindex(level.shape[:-1]):
+                a, _, t = s._walk(s.x, s.z, float(level[idx + (i,)]))
+                A[idx + (i,)], T[idx + (i,)] = a, t
+    return A, T
+
+
 def section_table(sections):
-    """list of TrapezoidalSection -> dict of arrays (rows of the FS_GEO_* table)."""
-    f = lambda get: np.array([get(s) for s in sections], dtype=np.float64)
-    return dict(
-        z_bed=f(lambda s: s.z_bed), b_main=f(lambda s: s.b_main), m_main=f(lambda s: s.m_main),
-        n_main=f(lambda s: s.n_main), n_left=f(lambda s: s.n_left), n_right=f(lambda s: s.n_right),
+    """list of sections -> dict of arrays: the rows of the FS_GEO_* table and, when any node is a
+    polyline, irr_x / irr_z [N, P] (rows padded with their last vertex), irr_npts [N] (0 for
+    trapezoid nodes) and irr_limits [N, 2] as fs_batch_set_geometry_irregular takes them."""
+    poly = [isinstance(s, IrregularSection) for s in sections]
+
+    def f(get, get_poly=lambda s: 0.0):
+        return np.array([get_poly(s) if p else get(s) for s, p in zip(sections, poly)], dtype=np.float64)
+    tab = dict(
+        z_bed=f(lambda s: s.z_bed, lambda s: s.z_min), b_main=f(lambda s: s.b_main), m_main=f(lambda s: s.m_main),
+        n_main=f(lambda s: s.n_main, lambda s: s.n_main), n_left=f(lambda s: s.n_left, lambda s: s.n_left),
+        n_right=f(lambda s: s.n_right, lambda s: s.n_right),
         is_compound=f(lambda s: 1.0 if s._is_compound else 0.0),
         h_bf=f(lambda s: s.bankfull_depth if s._is_compound else 0.0),
         b_fp_l=f(lambda s: s.b_fp_left), b_fp_r=f(lambda s: s.b_fp_right), m_fp=f(lambda s: s.m_fp),
-        curvature=f(lambda s: s.curvature))
+        curvature=f(lambda s: s.curvature, lambda s: s.curvature))
+    if any(poly):
+        P = max(s.x.size for s, p in zip(sections, poly) if p)
+        X = np.zeros((len(sections), P)); Z = np.zeros((len(sections), P))
+        cnt = np.zeros(len(sections), dtype=np.int32)
+        lim = np.zeros((len(sections), 2))
+        for i, (s, p) in enumerate(zip(sections, poly)):
+            if p:
+                cnt[i] = s.x.size
+                X[i, :cnt[i]], Z[i, :cnt[i]] = s.x, s.z
+                X[i, cnt[i]:], Z[i, cnt[i]:] = s.x[-1], s.z[-1]
+                lim[i] = (s.left_fp_limit, s.right_fp_limit)
+        tab.update(irr_x=X, irr_z=Z, irr_npts=cnt, irr_limits=lim)
+    return tab
 
 
 class CrossSection(ABC):
@@ -229,13 +265,143 @@ class TrapezoidalSection(CrossSection):
 
     def z_at(self, x):
         """Bed elevation at lateral coordinate x (cross_section.py:795-846)."""
-        x = abs(float(x))
+        x = float(x)
         half = self.b_main / 2.0
         if self._is_rect:
-            return self.z_bed if x < half else np.inf
-        if not self._is_compound or x <= self.T_main_at_bank / 2.0:
-            return self.z_bed if x <= half else self.z_bed + (x - half) / self.m_main
-        raise NotImplementedError("flood-plain z_at is only needed for mixed irregular interpolation")
+            return self.z_bed if abs(x) < half else np.inf
+        if not self._is_compound or abs(x) <= self.T_main_at_bank / 2.0:
+            return self.z_bed if abs(x) <= half else self.z_bed + (abs(x) - half) / self.m_main
+        # flood plains: flat bed of width b_fp_left / b_fp_right, then the outer wall at 1 : m_fp
+        beyond = abs(x) - self.T_main_at_bank / 2.0 - (self.b_fp_left if x < 0 else self.b_fp_right)
+        return self.z_bank if beyond <= 0 else self.z_bank + beyond / self.m_fp
+
+
+class IrregularSection(CrossSection):
+    """Section given by a polyline of (x, z) stations (cross_section.py:207-543): possibly several
+    wetted sub-channels, composite roughness over a left / main / right strip, finite-difference
+    dR/dA and dA/dh (dh = 1e-6).  Same numbers as the reference, including what it does with a
+    vertex lying exactly on the water surface and with the water's-edge points of temporary
+    sub-sections (see csrc/fs_poly.hpp, which evaluates the same thing on the device)."""
+    DH = 1e-6
+
+    def __init__(self, x, z, **kwargs):
+        super().__init__(**kwargs)
+        x = np.ascontiguousarray(x, dtype=float)
+        z = np.ascontiguousarray(z, dtype=float)
+        if x.shape != z.shape:
+            raise ValueError("x and z must have the same shape")
+        if x.ndim != 1:
+            raise ValueError("x and z must be 1-D arrays")
+        order = np.argsort(x, kind="stable")
+        self.x, self.z = x[order], z[order]
+        self._z_min = float(np.min(self.z))
+        self._width = float(self.x[-1] - self.x[0])
+        self.left_fp_limit, self.right_fp_limit = self.x[0], self.x[-1]
+
+    @property
+    def z_min(self):
+        return self._z_min
+
+    @property
+    def width(self):
+        return self._width
+
+    @staticmethod
+    def _walk(x, z, hw):
+        """(A, P, T) of the polyline (x, z) below stage hw, all edges at once: an edge counts in
+        full when both ends are wet, is cut at the surface when one end is wet and the other
+        strictly above, and is skipped otherwise (cross_section.py:262-322)."""
+        if x.size < 2:
+            return 0.0, 0.0, 0.0
+        x0, x1, z0, z1 = x[:-1], x[1:], z[:-1], z[1:]
+        d0, d1 = hw - z0, hw - z1
+        w0, w1 = d0 > 0.0, d1 > 0.0
+        full = w0 & w1
+        cut_l = w1 & (z0 > hw)
+        cut_r = w0 & (z1 > hw)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            xi = x0 + (hw - z0) / (z1 - z0) * (x1 - x0)           # where the edge meets the surface
+        dx = np.where(full, x1 - x0, np.where(cut_l, x1 - xi, np.where(cut_r, xi - x0, 0.0)))
+        dz = np.where(full, z1 - z0, np.where(cut_l, d1, np.where(cut_r, d0, 0.0)))
+        mean_d = np.where(full, 0.5 * (d0 + d1), np.where(cut_l, 0.5 * d1, np.where(cut_r, 0.5 * d0, 0.0)))
+        dx = np.where(full | cut_l | cut_r, dx, 0.0)
+        return float(np.sum(mean_d * dx)), float(np.sum(np.sqrt(dx * dx + dz * dz))), float(np.sum(dx))
+
+    def properties(self, hw):
+        A, P, T = self._walk(self.x, self.z, float(hw))
+        return (A, P, A / P if P > 0.0 else 0.0, T)
+
+    def get_subchannels(self, hw):
+        """Wetted runs of at least two stations with their water's-edge points (cross_section.py:330-370)."""
+        wet = np.concatenate(([False], self.z < hw, [False]))
+        starts = np.flatnonzero(wet[1:] & ~wet[:-1])
+        ends = np.flatnonzero(~wet[1:] & wet[:-1])               # one past the last wet station
+        out = []
+        n = self.x.size
+        for s, e in zip(starts, ends):
+            if e - s < 2:
+                continue
+            xs, zs = self.x[s:e], self.z[s:e]
+            if s > 0 and self.z[s - 1] > hw:
+                # the reference calls np.interp with a decreasing abscissa here, which lands on x[s]
+                xs, zs = np.r_[self.x[s], xs], np.r_[hw, zs]
+            if e < n and self.z[e - 1] < hw and self.z[e] > hw:
+                xe = (self.x[e] - self.x[e - 1]) / (self.z[e] - self.z[e - 1]) * (hw - self.z[e - 1]) + self.x[e - 1]
+                xs, zs = np.r_[xs, xe], np.r_[zs, hw]
+            out.append({"x": xs, "z": zs})
+        return out
+
+    def _strip_K(self, lo, hi, n_val, hw):
+        m = (self.x >= lo) & (self.x <= hi)
+        A, P, _ = self._walk(self.x[m], self.z[m], hw)
+        return hydraulics.conveyance(A=A, n=n_val, R=A / P) if (A > 0 and P > 0) else 0.0
+
+    def get_equivalent_n(self, hw):
+        """Horton-Einstein composite of the three strips (cross_section.py:449-503)."""
+        A, P, R, _ = self.properties(hw)
+        if A <= 0 or P <= 0:
+            return self.n_main
+        K = (self._strip_K(self.x[0], self.left_fp_limit, self.n_left, hw) ** 1.5
+             + self._strip_K(self.left_fp_limit, self.right_fp_limit, self.n_main, hw) ** 1.5
+             + self._strip_K(self.right_fp_limit, self.x[-1], self.n_right, hw) ** 1.5) ** (2.0 / 3.0)
+        return self.n_main if K <= 0.0 else (A * R ** (2.0 / 3.0)) / K
+
+    def conveyance(self, hw):
+        A, P, R, _ = self.properties(hw)
+        return 0.0 if A <= 0.0 else hydraulics.conveyance(A=A, n=self.get_equivalent_n(hw), R=R)
+
+    def dR_dA(self, hw, dh=DH):
+        A1, _, R1, _ = self.properties(hw - dh)
+        A2, _, R2, _ = self.properties(hw + dh)
+        return 0.0 if A2 - A1 == 0.0 else (R2 - R1) / (A2 - A1)
+
+    def dA_dh(self, hw, dh=DH):
+        return (self.area(hw + dh) - self.area(hw - dh)) / (2 * dh)
+
+    def dK_dA(self, hw):
+        A, P, R, _ = self.properties(hw)
+        if A <= 0.0:
+            return 0.0
+        return (R ** (2 / 3) + A * 2. / 3. * R ** (2 / 3 - 1) * self.dR_dA(hw)) / self.get_equivalent_n(hw)
+
+    def _channel_K(self, hw):
+        """Conveyance the friction slope uses: the whole section, or the 1.5-power sum over the
+        temporary sub-sections when the surface splits it (cross_section.py:372-392)."""
+        subs = self.get_subchannels(hw)
+        if len(subs) <= 1:
+            return self.conveyance(hw)
+        total = 0.0
+        for sc in subs:
+            part = IrregularSection(x=sc["x"], z=sc["z"])
+            part.set_roughness_para(self.get_roughness_para())
+            total += part.conveyance(hw) ** 1.5
+        return total ** (2.0 / 3.0)
+
+    def friction_slope(self, h, Q):
+        return hydraulics.Sf(Q=Q, K=self._channel_K(h + self.z_min))
+
+    def z_at(self, x):
+        return np.interp(x, self.x, self.z, left=self.z[0], right=self.z[-1])
 
 
 def interpolate_cross_section(xs1: CrossSection, xs2: CrossSection, dist1: float, dist2: float) -> CrossSection:
@@ -247,10 +413,22 @@ def interpolate_cross_section(xs1: CrossSection, xs2: CrossSection, dist1: float
         return xs1
     if dist2 < 1e-9:
         return xs2
-    if not (isinstance(xs1, TrapezoidalSection) and isinstance(xs2, TrapezoidalSection)):
-        raise NotImplementedError("interpolation with IrregularSection is not provided yet (SURVEY.md 8f rank 2)")
     w1, w2 = dist2 / total, dist1 / total
     mix = lambda a, b: a * w1 + b * w2
+    if not (isinstance(xs1, TrapezoidalSection) and isinstance(xs2, TrapezoidalSection)):
+        # at least one polyline: blend bed elevations over the union of the polyline stations
+        # (cross_section.py:932-968); a trapezoid neighbour is sampled through its z_at()
+        stations = [s.x for s in (xs1, xs2) if isinstance(s, IrregularSection)]
+        if not stations:
+            raise TypeError("Cannot interpolate: no x-coordinates found.")
+        xm = stations[0] if len(stations) == 1 else np.union1d(stations[0], stations[1])
+        zm = np.array([xs1.z_at(v) for v in xm]) * w1 + np.array([xs2.z_at(v) for v in xm]) * w2
+        slope = None if (xs1.bed_slope is None or xs2.bed_slope is None) else mix(xs1.bed_slope, xs2.bed_slope)
+        new = IrregularSection(x=xm, z=zm, n=mix(xs1.n_main, xs2.n_main), bed_slope=slope,
+                               curvature=mix(xs1.curvature, xs2.curvature))
+        new.set_roughness_para((mix(xs1.n_left, xs2.n_left), mix(xs1.n_main, xs2.n_main), mix(xs1.n_right, xs2.n_right),
+                                mix(xs1.left_fp_limit, xs2.left_fp_limit), mix(xs1.right_fp_limit, xs2.right_fp_limit)))
+        return new
     y1 = (xs1.z_bank - xs1.z_bed) if xs1._is_compound else 0.0
     y2 = (xs2.z_bank - xs2.z_bed) if xs2._is_compound else 0.0
     z_bed = mix(xs1.z_bed, xs2.z_bed)

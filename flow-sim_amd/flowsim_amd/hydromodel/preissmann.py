@@ -41,14 +41,17 @@ class PreissmannSolver(Solver):
         ch = self.channel
         N, nt = self.number_of_nodes, self.number_of_time_levels
         geo = ch.node_geometry
-        rect = (np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)
+        rect = ("irr_npts" not in geo and np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)
                 and np.ptp(geo["b_main"]) == 0 and np.ptp(geo["n_main"]) == 0 and ch.input_xs is not None
                 and len(ch.input_xs) == 2)
-        with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode="rect_uniform" if rect else "table",
-                             history=True, trace=(verbose == 3)) as b:
+        poly = "irr_npts" in geo                   # any IrregularSection node (cross_section.py:207-543)
+        mode = "irregular" if poly else ("rect_uniform" if rect else "table")
+        with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode=mode, history=True, trace=(verbose == 3)) as b:
             b.set_scheme(self.theta, self.time_step, self.spatial_step, tolerance, max_iter)
             if rect:
                 b.set_geometry_uniform(geo["b_main"][0], geo["n_main"][0], geo["z_bed"][0], geo["z_bed"][-1])
+            elif poly:
+                b.set_geometry_irregular(geo)
             else:
                 b.set_geometry_table(geo)
             b.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step))
@@ -98,7 +101,7 @@ class PreissmannSolver(Solver):
         """Froude diagnosis printed before a convergence failure is raised (preissmann.py:179-198)."""
         geo = self.channel.node_geometry
         k = self.time_level
-        A_, P, R, T, _ = XS.props(geo, self.depth[k] + geo["z_bed"])
+        A_, T = XS.area_top(self.channel.xs_at_node, geo, self.depth[k] + geo["z_bed"])
         fr = froude_array(T, A_, self.flow[k])
         bad = False
         for x, f in zip(self.channel.ch_at_node, fr):

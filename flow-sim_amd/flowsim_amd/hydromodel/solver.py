@@ -106,7 +106,7 @@ class Solver(ABC):
         """the same fields with numpy (used when no device history is available, e.g. after a failed run)"""
         geo = self.channel.node_geometry
         self.level = self.depth + self.bed_profile
-        A, P, R, T, _ = XS.props({n: v[None, :] for n, v in geo.items()}, self.level)
+        A, T = XS.area_top(self.channel.xs_at_node, geo, self.level)
         self.area, self.top_width = A, T
         self.froude_number = hydraulics.froude_array(T, A, self.flow)
         self.velocity = self.flow / self.area

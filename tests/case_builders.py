@@ -5,8 +5,8 @@ from math import cos, pi, sin
 
 import numpy as np
 
-from flowsim_amd.hydromodel import (Boundary, Channel, Hydrograph, LumpedStorage, PreissmannSolver, RatingCurve,
-                                    TrapezoidalSection)
+from flowsim_amd.hydromodel import (Boundary, Channel, Hydrograph, IrregularSection, LumpedStorage, PreissmannSolver,
+                                    RatingCurve, TrapezoidalSection)
 
 
 def akbari_shape(Q_b, Q_p, t_p, t_b):
@@ -108,5 +108,59 @@ def gerd_member(n_main):
     return solver, S.tolerance
 
 
-BUILDERS = {"gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
+def irr_single():
+    """two polylines with different stations, one thalweg (tests/golden/irr_single.npz)"""
+    L = 6000.0; S0 = 2e-4
+    xu = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); zu = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
+    xd = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zd = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
+    xs_u = IrregularSection(x=xu, z=S0 * L + zu, n=0.03, bed_slope=S0)
+    xs_d = IrregularSection(x=xd, z=zd, n=0.034, bed_slope=S0)
+    hyd = Hydrograph(akbari_shape(40.0, 260.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L)
+    ch = Channel(initial_flow=40.0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.65, time_step=300, spatial_step=500, simulation_time=3 * 3600), 1e-6
+
+
+def irr_levee():
+    """secondary channel behind a levee, composite roughness, power rating curve (tests/golden/irr_levee.npz)"""
+    L = 5000.0; S0 = 3e-4
+    x = np.array([0, 8, 12, 28, 32, 44, 50, 62, 70, 84.0])
+    z = np.array([7, 3.2, 0.5, 0.0, 0.7, 2.6, 1.1, 1.3, 2.9, 7.0])
+    xs_u = IrregularSection(x=x, z=S0 * L + z, n=0.03, bed_slope=S0)
+    xs_u.set_roughness_para((0.05, 0.03, 0.06, 12.0, 44.0))
+    xs_d = IrregularSection(x=x * 1.1, z=z * 0.95, n=0.032, bed_slope=S0)
+    xs_d.set_roughness_para((0.05, 0.032, 0.055, 13.2, 48.4))
+    rc = RatingCurve(); rc.set(type='power', a=14.0, b=1.9)
+    h_ds = 1.6
+    Q0 = rc.discharge(h_ds)
+    hyd = Hydrograph(akbari_shape(Q0, 6.0 * Q0, 1.5 * 3600.0, 4 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_ds, rating_curve=rc)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='linear')
+    us.initial_depth = 1.7
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=300, spatial_step=500, simulation_time=4 * 3600), 1e-6
+
+
+def irr_mixed():
+    """trapezoid -> polyline -> polyline along a bending centre line (tests/golden/irr_mixed.npz)"""
+    L = 8000.0; S0 = 2.5e-4
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=30.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    xm = np.array([-40, -25, -16, -6, 5, 17, 26, 41.0]); zm = np.array([6, 2.2, 0.5, 0.0, 0.1, 0.6, 2.4, 6.0])
+    xs_m = IrregularSection(x=xm, z=S0 * L * 0.5 + zm, n=0.031, bed_slope=S0)
+    xd = np.array([-45, -22, -15, -4, 8, 19, 30, 46.0]); zd = np.array([6, 2.0, 0.4, 0.0, 0.2, 0.7, 2.1, 6.0])
+    xs_d = IrregularSection(x=xd, z=zd, n=0.033, bed_slope=S0)
+    hyd = Hydrograph(akbari_shape(60.0, 200.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L)
+    ch = Channel(initial_flow=60.0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, 0.5 * L, L], [xs_u, xs_m, xs_d])
+    ch.set_coords([[0.0, 0.0], [2500.0, 300.0], [4000.0, 1500.0], [4200.0, 3800.0], [6500.0, 5200.0]],
+                  [0.0, 2500.0, 4400.0, 6700.0, L])
+    return PreissmannSolver(channel=ch, theta=0.65, time_step=300, spatial_step=500, simulation_time=3 * 3600), 1e-6
+
+
+BUILDERS = {"irr_single": irr_single, "irr_levee": irr_levee, "irr_mixed": irr_mixed, "gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
             "bc_compound_normal": bc_compound_normal}

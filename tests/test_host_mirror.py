@@ -21,6 +21,13 @@ def check(solver, fx, meta, mem=None):
     ch = solver.channel
     for k in GEO:
         np.testing.assert_allclose(ch.node_geometry[k], pick("geo_" + k), rtol=1e-13, atol=1e-15, err_msg=k)
+    if "geo_irr_npts" in fx.files:                       # polyline nodes (IrregularSection + mixed interpolation)
+        cnt = fx["geo_irr_npts"]
+        assert np.array_equal(ch.node_geometry["irr_npts"], cnt)
+        for i, c in enumerate(cnt):
+            np.testing.assert_allclose(ch.node_geometry["irr_x"][i, :c], fx["geo_irr_x"][i, :c], rtol=1e-14, atol=1e-14)
+            np.testing.assert_allclose(ch.node_geometry["irr_z"][i, :c], fx["geo_irr_z"][i, :c], rtol=1e-14, atol=1e-14)
+        np.testing.assert_allclose(ch.node_geometry["irr_limits"], fx["geo_irr_limits"], rtol=1e-14)
     np.testing.assert_allclose(ch.ch_at_node, pick("geo_chainage"), rtol=1e-14)
     np.testing.assert_allclose(ch.initial_conditions, pick("initial_conditions"), rtol=1e-11, atol=1e-13)
     if ch.upstream_boundary.hydrograph is not None:
@@ -34,6 +41,27 @@ def test_setup_matches_reference(name):
     solver, tol = CB.BUILDERS[name]()
     assert tol == meta["tolerance"] and solver.theta == meta["theta"]
     check(solver, fx, meta)
+
+
+@pytest.mark.parametrize("name", ["irr_single", "irr_levee", "irr_mixed"])
+def test_polyline_section_methods_match_reference_probe(name):
+    """IrregularSection of the mirror against the reference's own methods at several stages per node."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, _ = CB.BUILDERS[name]()
+    xs = solver.channel.xs_at_node
+    multi = 0
+    for row in fx["probe"]:
+        s = xs[int(row[0])]
+        h, Q = row[1], row[2]
+        hw = s.z_min + h
+        got = [s.area(hw), s.wetted_perimeter(hw), s.top_width(hw), s.dA_dh(hw), s.get_equivalent_n(hw),
+               s.conveyance(hw), s.dR_dA(hw), s.dK_dA(hw), s.friction_slope(h, Q)]
+        tol = [1e-13, 1e-13, 1e-13, 5e-9, 1e-13, 1e-13, 5e-9, 5e-9, 1e-12]
+        for g, r, t in zip(got, row[3:12], tol):
+            assert abs(g - r) <= t * max(abs(r), 1e-300), (name, row[:3], g, r)
+        assert abs(s.curvature_slope(h, Q) - row[14]) <= 1e-12 * max(abs(row[14]), 1e-30)
+        multi += hasattr(s, "get_subchannels") and len(s.get_subchannels(hw)) > 1
+    assert (multi > 0) == (name == "irr_levee")
 
 
 def test_synthetic_trapezoid_members():
