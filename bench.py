@@ -85,10 +85,12 @@ def main():
     ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU")
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c4"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c4", "irr"],
                     help="c3: rectangular, normal-depth outflow (the headline config); c5: SURVEY 8d trapezoid + power "
                          "rating curve (use with --dtype f32 --nodes 512 --reaches 131072); c4: cases/gerd_roseires "
-                         "geometry with a Manning-n Monte-Carlo ensemble (use with --reaches 32768; nodes fixed at 121)")
+                         "geometry with a Manning-n Monte-Carlo ensemble (use with --reaches 32768; nodes fixed at 121); irr: "
+                         "polyline (IrregularSection) channel with a levee, Manning-n ensemble (use with --reaches 8192; "
+                         "129 nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -152,6 +154,40 @@ def main():
         Qb = None
         desc = ("C4: cases/gerd_roseires (121 nodes, compound sections + curvature, Roseires gate curve), %d-member "
                 "Manning-n ensemble per GPU, theta 0.6, dt 3600 s, tol 1e-6" % B)
+    elif args.workload == "irr":
+        # polyline sections (8 -> 15 stations after interpolation, berm on the right bank),
+        # composite roughness over three strips, one channel shared by a Manning-n ensemble
+        from flowsim_amd.hydromodel import Boundary, Channel, Hydrograph, IrregularSection, PreissmannSolver
+        from flowsim_amd.hydromodel.preissmann import boundary_to_spec
+        Lc, S0c = 64000.0, 3e-4
+        xa = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); za = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
+        xb = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zb = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
+        secs = []
+        for f, xx, zz in ((1.0, xa, za), (0.5, xb, zb), (0.0, xa * 1.1, za * 0.95)):
+            s_ = IrregularSection(x=xx, z=S0c * Lc * f + zz, n=0.03, bed_slope=S0c)
+            s_.set_roughness_para((0.05, 0.03, 0.06, xx[2], xx[5]))
+            secs.append(s_)
+        Q0 = 45.0
+        hyd = Hydrograph(table=np.column_stack([np.arange(levels + 1) * 300.0,
+                                                Q0 * (1.0 + 2.0 * np.sin(np.pi * np.arange(levels + 1) / max(levels, 2)) ** 2)]))
+        us = Boundary(condition='flow_hydrograph', bed_level=S0c * Lc, chainage=0, hydrograph=hyd, initial_depth=1.9)
+        ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=Lc, initial_depth=1.9)
+        ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+        ch.set_cross_sections([0.0, 0.5 * Lc, Lc], secs)
+        solver = PreissmannSolver(channel=ch, theta=0.7, time_step=300, spatial_step=500, simulation_time=(levels - 1) * 300)
+        N = solver.number_of_nodes
+        rng = np.random.default_rng(20260216)
+        n_members = (0.025 + 0.015 * rng.random(first + B))[first:]
+        theta, dt, dx, tol = 0.7, 300.0, solver.spatial_step, 1e-6
+        batch = PreissmannBatch(B, N, levels, dtype="f64", section_mode="irregular", device=local)
+        batch.set_scheme(theta, dt, dx, tol, 100)
+        batch.set_geometry_irregular(ch.node_geometry, n_main_override=n_members)
+        batch.set_boundary(A.UPSTREAM, boundary_to_spec(us, levels, dt))
+        batch.set_boundary(A.DOWNSTREAM, boundary_to_spec(ds, levels, dt))
+        batch.set_state(ch.initial_conditions[:, 0], ch.initial_conditions[:, 1])
+        Qb = None
+        desc = ("IRR: polyline channel (%d nodes, 8-15 stations per section, composite roughness over three strips)"
+                ", %d-member Manning-n ensemble per GPU, theta 0.7, dt 300 s, tol 1e-6" % (N, B))
     else:
         theta, dt, dx = 0.6, 1800.0, 500.0
         tol = 1e-3 if args.dtype == "f32" else 1e-6
@@ -165,7 +201,7 @@ def main():
                                                                             stage_shift=np.zeros(B), bed_level=np.zeros(B))))
         desc = ("C5: %d synthetic trapezoidal reaches x %d nodes per GPU, power rating-curve downstream, theta 0.6, "
                 "dt 1800 s, dx 500 m, tol %g" % (B, N, tol))
-    if args.workload != "c4":
+    if args.workload not in ("c4", "irr"):
         batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
         batch.set_state_uniform(hn, Qb)
     batch.sync()
@@ -226,6 +262,7 @@ def main():
         alg_bytes_launch = float(B) * K * (4 * N * real + 8 + 32)      # state in+out, BC target, hydrograph row
         ach = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
         mean_its = float(it_t[0].item()) / total
+        status_counts = {int(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}
         out = {
             "metric": "reach-timesteps/sec (batched Preissmann Newton step)",
             "value": total / el, "unit": "reach-timesteps/s", "n_gpus": world, "steps": K, "warmup": Wm,
@@ -234,6 +271,7 @@ def main():
             "config": {"workload": desc,
                        "reaches_per_gpu": B, "nodes": N, "parallelism": f"reach-sharded x{world}",
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
+                       "status_counts_rank0": status_counts,
                        "kernel": info},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
