@@ -478,6 +478,62 @@ def case_irregular():
     run("irr_mixed", ch, 0.65, 300, 500, 3 * 3600, hyd)
 
 
+def case_storage_general():
+    """fixed_depth behind a LumpedStorage with an area curve, a reservoir rating
+    curve and entrance losses (lumped_storage.py:24-179, boundary.py:97-133, :152-164, :213-237):
+    the mass-balance root needs brentq, the interface stage carries friction + empirical head loss."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.lumped_storage import LumpedStorage
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.rating_curve import RatingCurve
+    from src.hydromodel.cross_section import TrapezoidalSection
+
+    def run(name, rc_type, losses, trap):
+        L = 10000.0
+        Qb = 200.0
+        hyd = Hydrograph(akbari_hydrograph(Qb, 900.0, 3 * 3600.0, 9 * 3600.0))
+        us = Boundary(condition='flow_hydrograph', bed_level=2.0, chainage=0, hydrograph=hyd)
+        ds = Boundary(condition='fixed_depth', initial_depth=5, bed_level=0, chainage=L)
+        stages = np.arange(0.0, 30.01, 0.5)
+        curve = np.column_stack([stages, 2.0e5 + 4.0e4 * stages + 900.0 * stages ** 2])
+        rc = None
+        meta = dict(storage_curve=curve.tolist(), storage_alpha=1.1, storage_beta=0.2, storage_min_stage=4.0,
+                    ds_initial_depth=5.0, storage_rc_type=rc_type)
+        if rc_type == 'polynomial':
+            rc = RatingCurve(); rc.set(type='polynomial', a=6.0, b=10.0, c=0.0)
+            meta.update(storage_rc=dict(a=6.0, b=10.0, c=0.0, shift=0.0))
+        elif rc_type == 'power':
+            rc = RatingCurve(); rc.set(type='power', a=17.0, b=1.5)
+            meta.update(storage_rc=dict(a=17.0, b=1.5, shift=0.0))
+        ss = LumpedStorage(surface_area=None, min_stage=4.0, solution_boundaries=(0, 30), rating_curve=rc)
+        ss.set_area_curve(curve, alpha=1.1, beta=0.2)
+        if losses:
+            ss.capture_losses = True
+            ss.reservoir_length = 800.0
+            ss.K_q = 0.3
+            meta.update(storage_losses=dict(reservoir_length=800.0, K_q=0.3))
+        meta["storage_bounds"] = [float(ss.Y_min), float(ss.Y_max)]
+        ds.set_lumped_storage(ss)
+        if trap:
+            xs_u = TrapezoidalSection(z_bed=2.0, b_main=90.0, m_main=2.0, n_main=0.028, bed_slope=2e-4)
+            xs_d = TrapezoidalSection(z_bed=0.0, b_main=110.0, m_main=2.5, n_main=0.03, bed_slope=2e-4)
+            ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds)
+            ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+        else:
+            ch = Channel(width=100, initial_flow=Qb, roughness=0.03, upstream_boundary=us, downstream_boundary=ds)
+        sol = PreissmannSolver(channel=ch, theta=0.7, time_step=1200, spatial_step=500, simulation_time=12 * 3600)
+        out, wall = run_and_capture(sol, 1e-6)
+        out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+        out["storage_stage"] = np.array(ss.stage_hydrograph, dtype=np.float64)[1:]
+        save(name, out, base_meta(sol, 1e-6, wall, **meta))
+
+    run("storage_curve_poly_losses", 'polynomial', True, False)
+    run("storage_curve_power_trap", 'power', True, True)
+    run("storage_curve_closed", None, False, False)
+
+
 def _gerd_imports():
     """cwd + read_csv shim for cases/gerd_roseires (harness only)."""
     os.chdir(REF)
@@ -603,6 +659,7 @@ CASES = {
     "synthetic_trap_64": lambda: synthetic_trap("synthetic_trap_64", 4, 64, 5, 20260214),
     "bc_matrix": case_bc_matrix,
     "irregular": case_irregular,
+    "storage_general": case_storage_general,
 }
 
 if __name__ == "__main__":

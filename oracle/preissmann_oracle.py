@@ -314,6 +314,46 @@ def rating_dQ_dz(bc: BC, stage):
     return (rating_discharge(bc, stage + dY) - rating_discharge(bc, stage - dY)) / (2 * dY)
 
 
+def storage_area_at(st, Y):
+    """lumped_storage.py:152-157."""
+    if st.get("curve") is None:
+        return st["area"]
+    c = st["curve"]
+    return st["alpha"] * np.interp(Y + st["beta"], c[:, 0], c[:, 1])
+
+
+def storage_net_vol(st, Y1, Y2):
+    """lumped_storage.py:166-179 (incl. the n-point trapezoid whose n depends on |Y2 - Y1|)."""
+    if st.get("curve") is None:
+        return (Y2 - Y1) * st["area"]
+    c = st["curve"]
+    step = np.min(np.abs(c[1:, 0] - c[:-1, 0]))
+    n = int(abs(Y2 - Y1) / step)
+    if n > 2:
+        ys = np.linspace(Y1, Y2, n)
+        return np.trapezoid([storage_area_at(st, y) for y in ys], ys)
+    return 0.5 * (storage_area_at(st, Y2) + storage_area_at(st, Y1)) * (Y2 - Y1)
+
+
+def storage_outflow(st, Y):
+    rc = st.get("rc")                                                # rating_curve.py:32-63
+    if rc is None:
+        return 0.0
+    x = Y + rc.get("shift", 0.0)
+    return rc["a"] * x ** 2 + rc["b"] * x + rc["c"] if rc["type"] == "polynomial" else rc["a"] * x ** rc["b"]
+
+
+def storage_mass_balance(st, dt, vol_in, Y_old):
+    """lumped_storage.py:24-35: the reference's own root finder (scipy.optimize.brentq, default tolerances)."""
+    from scipy.optimize import brentq
+
+    def f(Y_new):
+        q_out = 0.5 * (storage_outflow(st, Y_old) + storage_outflow(st, Y_new)) if st.get("rc") is not None else 0.0
+        return storage_net_vol(st, Y_old, Y_new) - (vol_in - q_out * dt)
+    Y = brentq(f, st["Y_min"], st["Y_max"])
+    return st["min_stage"] if Y < st["min_stage"] else Y
+
+
 def boundary_eval(bc: BC, geo_node, h, Q, k, dt, Q_old=None, store=None):
     """(residual, d/dh, d/dQ) of one boundary equation at time level k.  boundary.py:56-242.
 
@@ -344,15 +384,34 @@ def boundary_eval(bc: BC, geo_node, h, Q, k, dt, Q_old=None, store=None):
         st = bc.storage
         vol_in = 0.5 * (Q_old + Q) * dt                                    # preissmann.py:314
         Y_old = (h + bc.bed_level) if k == 1 else store["Y_prev"]          # boundary.py:104-108
-        Y_new = Y_old + vol_in / st["area"]            # root of lumped_storage.py:25-28 with :170
-        if not (st["Y_min"] <= Y_new <= st["Y_max"]):
-            raise ValueError("f(a) and f(b) must have different signs")   # what brentq raises
-        clamped = Y_new < st["min_stage"]
-        if clamped:
-            Y_new = st["min_stage"]
+        general = st.get("curve") is not None or st.get("rc") is not None or st.get("losses") is not None
+        if general:
+            Y_new = storage_mass_balance(st, dt, vol_in, Y_old)            # lumped_storage.py:24-35 (brentq)
+        else:
+            Y_new = Y_old + vol_in / st["area"]        # root of lumped_storage.py:25-28 with :170
+            if not (st["Y_min"] <= Y_new <= st["Y_max"]):
+                raise ValueError("f(a) and f(b) must have different signs")   # what brentq raises
+            if Y_new < st["min_stage"]:
+                Y_new = st["min_stage"]
         store["Y_eval"] = Y_new
-        dY = 0.0 if Y_new <= st["min_stage"] else 1.0 / st["area"]         # lumped_storage.py:37-45
-        return h - (Y_new - bc.bed_level), 1.0, 0.0 - dY * 0.5 * dt
+        dY = 0.0 if Y_new <= st["min_stage"] else 1.0 / storage_area_at(st, Y_new)     # lumped_storage.py:37-45
+        hl = dhl_dA = dhl_dQ = 0.0
+        dA_dh = 0.0
+        if st.get("losses") is not None:                                   # boundary.py:118-124, :152-164, :230-235
+            Lr, Kq = st["losses"]["reservoir_length"], st["losses"]["K_q"]
+            r = node_terms(geo_node, np.array([h]), np.array([Q]))                          # hw = z_min + depth
+            A, R, n = float(r["A"][0]), float(r["R"][0]), float(r["n_eq"][0])
+            hl = Q * abs(Q) / _k(A, n, R) ** 2 * Lr + Kq * (Q / A) ** 2 / (2 * G)
+            d = node_terms(geo_node, np.array([h + bc.bed_level - z_min]), np.array([Q]))  # hw = depth + bed_level
+            A, R, n = float(d["A"][0]), float(d["R"][0]), float(d["n_eq"][0])
+            dRdA = float(dR_dA(geo_node, None, section_props(geo_node, np.array([h + bc.bed_level - z_min])))[0])
+            K = _k(A, n, R)
+            dK = (R ** (2.0 / 3.0) + A * 2.0 / 3.0 * R ** (2.0 / 3.0 - 1) * dRdA) / n
+            V = Q / A
+            dhl_dA = -2 * (Q * abs(Q) / K ** 2) * (dK / K) * Lr + Kq * 2 * V * (-Q / A ** 2) / (2 * G)
+            dhl_dQ = 2 * abs(Q) / K ** 2 * Lr + Kq * 2 * V * (1.0 / A) / (2 * G)
+            dA_dh = float(d["T"][0])
+        return h - (Y_new + hl - bc.bed_level), 1.0 - dhl_dA * dA_dh, 0.0 - (dY * 0.5 * dt + dhl_dQ)
     raise ValueError("Invalid boundary condition.")
 
 
@@ -508,9 +567,16 @@ def problem_from_fixture(fx, meta, member=None):
             else:
                 prm = pick("params")
                 bc.rc_type, bc.rc = "power", dict(a=float(prm[6]), b=float(prm[7]), shift=0.0)
-        if kind == "fixed_depth" and "storage_area" in meta:
-            bc.storage = dict(area=meta["storage_area"], min_stage=meta["storage_min_stage"],
+        if kind == "fixed_depth" and ("storage_area" in meta or "storage_curve" in meta):
+            bc.storage = dict(area=meta.get("storage_area"), min_stage=meta["storage_min_stage"],
                               Y_min=meta["storage_bounds"][0], Y_max=meta["storage_bounds"][1])
+            if "storage_curve" in meta:
+                bc.storage.update(curve=np.array(meta["storage_curve"], dtype=np.float64),
+                                  alpha=meta["storage_alpha"], beta=meta["storage_beta"])
+            if meta.get("storage_rc_type"):
+                bc.storage["rc"] = dict(type=meta["storage_rc_type"], **meta["storage_rc"])
+            if "storage_losses" in meta:
+                bc.storage["losses"] = meta["storage_losses"]
         return bc
     return Problem(geo=geo, h0=np.array(ic[:, 0]), Q0=np.array(ic[:, 1]), us=mk("us"), ds=mk("ds"),
                    theta=meta["theta"], dt=meta["dt"], dx=meta["dx"], nt=meta["nt"],
