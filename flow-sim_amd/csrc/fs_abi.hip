@@ -361,12 +361,22 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
   if (!b) return fail("null handle");
   if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: side must be FS_UPSTREAM or FS_DOWNSTREAM");
   static const int need[] = {0, 1, 1, 2, 4, 5, 10, 5};
-  if (kind < 0 || kind > FS_BC_STORAGE) return fail("Invalid boundary condition.");              // boundary.py:33
-  if (n_params != need[kind]) return fail("Insufficient arguments for boundary condition.");      // boundary.py:83
+  if (kind < 0 || kind > FS_BC_STORAGE_CURVE) return fail("Invalid boundary condition.");        // boundary.py:33
+  if (kind == FS_BC_STORAGE_CURVE) {
+    if (per_reach) return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE parameters are shared by the batch (per_reach = 0)");
+    if (!params || n_params < FS_SC_NFIXED) return fail("Insufficient arguments for boundary condition.");
+    const int nc = (int)params[FS_SC_N_CURVE];
+    if (nc < 0 || nc == 1 || n_params != FS_SC_NFIXED + 2 * nc)
+      return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE needs FS_SC_NFIXED + 2*n_curve parameters (n_curve 0 or >= 2)");
+    for (int j = 0; j + 1 < nc; ++j)
+      if (!(params[FS_SC_NFIXED + j + 1] > params[FS_SC_NFIXED + j]))
+        return fail("fs_batch_set_bc: area-curve stages must be increasing");
+    if (nc == 0 && !(params[FS_SC_SURFACE_AREA] > 0)) return fail("Insufficient arguments for boundary condition.");
+  } else if (n_params != need[kind]) return fail("Insufficient arguments for boundary condition.");      // boundary.py:83
   if (n_params > 0 && !params) return fail("Insufficient arguments for boundary condition.");
   if ((kind == FS_BC_FLOW_HYDROGRAPH || kind == FS_BC_STAGE_HYDROGRAPH) && !target)
     return fail("Insufficient arguments for boundary condition.");                                // boundary.py:87
-  if (kind == FS_BC_STORAGE && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
+  if (fs::bc_is_storage(kind) && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
   const size_t B = b->d.n_reaches;
   if (b->bc_params[side]) { hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
   if (b->bc_target[side]) { hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }

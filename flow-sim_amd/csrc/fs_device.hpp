@@ -330,6 +330,162 @@ __device__ __forceinline__ R rating_blend(R z, R s0, R buf, R l0, R l1, R l2, R 
   return (R(1) - al) * lo + al * hi;
 }
 
+// ---- general LumpedStorage behind a fixed_depth boundary (FS_BC_STORAGE_CURVE) ----
+// what the entrance-loss terms need from the boundary node's section at one stage
+template <typename R> struct EntryProps { R A, Rh, neq, dRdA, dAdh; };
+
+template <typename R> struct StorageCurve {
+  const BCDesc<R> &bc; int reach, B, nc;
+  __device__ __forceinline__ R p(int i) const { return bc_param(bc, i, reach, B); }
+  __device__ __forceinline__ R xs(int j) const { return p(FS_SC_NFIXED + j); }
+  __device__ __forceinline__ R ys(int j) const { return p(FS_SC_NFIXED + nc + j); }
+  // lumped_storage.py:152-157 (np.interp: clamped outside the table)
+  __device__ R area_at(R Y) const {
+    if (nc == 0) return p(FS_SC_SURFACE_AREA);
+    const R x = Y + p(FS_SC_BETA);
+    R a;
+    if (x <= xs(0)) a = ys(0);
+    else if (x >= xs(nc - 1)) a = ys(nc - 1);
+    else {
+      int lo = 0, hi = nc - 1;
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (xs(mid) <= x) lo = mid; else hi = mid; }
+      const R slope = (ys(lo + 1) - ys(lo)) / (xs(lo + 1) - xs(lo));
+      a = slope * (x - xs(lo)) + ys(lo);
+    }
+    return p(FS_SC_ALPHA) * a;
+  }
+  // lumped_storage.py:166-179: n-point trapezoid over np.linspace(Y1, Y2, n) when n = int(|Y2-Y1|/step) > 2
+  __device__ R net_vol(R Y1, R Y2, R step) const {
+    if (nc == 0) return (Y2 - Y1) * p(FS_SC_SURFACE_AREA);
+    const int n = (int)(fabs_(Y2 - Y1) / step);
+    if (n > 2) {
+      const R d = (Y2 - Y1) / R(n - 1);
+      R sum = R(0), y0 = Y1, a0 = area_at(Y1);
+      for (int i = 1; i < n; ++i) {
+        const R y1 = i == n - 1 ? Y2 : Y1 + R(i) * d;
+        const R a1 = area_at(y1);
+        sum += (y1 - y0) * (a1 + a0) / R(2);
+        y0 = y1; a0 = a1;
+      }
+      return sum;
+    }
+    return R(0.5) * (area_at(Y2) + area_at(Y1)) * (Y2 - Y1);
+  }
+  __device__ R outflow(R Y) const {                                     // rating_curve.py:50-61
+    const int type = (int)p(FS_SC_RC_TYPE);
+    if (type == 0) return R(0);
+    const R x = Y + p(FS_SC_RC_SHIFT);
+    return type == 2 ? p(FS_SC_RC_A) * x * x + p(FS_SC_RC_B) * x + p(FS_SC_RC_C) : p(FS_SC_RC_A) * pow_(x, p(FS_SC_RC_B));
+  }
+};
+
+// Root of the reservoir mass balance on [Y_min, Y_max] (lumped_storage.py:24-31).  The reference calls
+// scipy.optimize.brentq with its defaults (xtol 2e-12, rtol 4 eps, 100 iterations); this is that
+// published algorithm (Brent 1973 as arranged in scipy/optimize/Zeros/brentq.c: bisection guarded
+// secant / inverse quadratic extrapolation on a bracketing triple), so the iterates - and with them
+// where the n-point trapezoid of net_vol switches its n - follow the reference's.
+template <typename R>
+__device__ R storage_root(const StorageCurve<R> &sc, R Yold, R vol_in, R dt, R step, int *flag) {
+  const R qold = sc.outflow(Yold);
+  const bool has_rc = (int)sc.p(FS_SC_RC_TYPE) != 0;
+  auto f = [&](R Y) {
+    const R qout = has_rc ? R(0.5) * (qold + sc.outflow(Y)) : R(0);
+    return sc.net_vol(Yold, Y, step) - (vol_in - qout * dt);
+  };
+  const R xtol = R(2e-12), rtol = R(8.881784197001252e-16);
+  R xpre = sc.p(FS_SC_Y_MIN), xcur = sc.p(FS_SC_Y_MAX), xblk = R(0);
+  R fpre = f(xpre), fcur = f(xcur), fblk = R(0), spre = R(0), scur = R(0);
+  if (fpre == R(0)) return xpre;
+  if (fcur == R(0)) return xcur;
+  if ((fpre < R(0)) == (fcur < R(0)) || !(fpre == fpre) || !(fcur == fcur)) {   // brentq: "f(a) and f(b) must have different signs"
+    *flag = FS_STORAGE_RANGE;
+    return xcur;
+  }
+  for (int it = 0; it < 100; ++it) {
+    if (fpre != R(0) && fcur != R(0) && ((fpre < R(0)) != (fcur < R(0)))) {
+      xblk = xpre; fblk = fpre;
+      spre = scur = xcur - xpre;
+    }
+    if (fabs_(fblk) < fabs_(fcur)) {
+      xpre = xcur; xcur = xblk; xblk = xpre;
+      fpre = fcur; fcur = fblk; fblk = fpre;
+    }
+    const R delta = (xtol + rtol * fabs_(xcur)) / R(2);
+    const R sbis = (xblk - xcur) / R(2);
+    if (fcur == R(0) || fabs_(sbis) < delta) return xcur;
+    if (fabs_(spre) > delta && fabs_(fcur) < fabs_(fpre)) {
+      R stry;
+      if (xpre == xblk) {
+        stry = -fcur * (xcur - xpre) / (fcur - fpre);                    // secant
+      } else {
+        const R dpre = (fpre - fcur) / (xpre - xcur), dblk = (fblk - fcur) / (xblk - xcur);
+        stry = -fcur * (fblk * dblk - fpre * dpre) / (dblk * dpre * (fblk - fpre));   // inverse quadratic
+      }
+      const R lim = fmin(fabs_(spre), R(3) * fabs_(sbis) - delta);
+      if (R(2) * fabs_(stry) < lim) { spre = scur; scur = stry; }
+      else { spre = sbis; scur = sbis; }
+    } else {
+      spre = sbis; scur = sbis;
+    }
+    xpre = xcur; fpre = fcur;
+    if (fabs_(scur) > delta) xcur += scur;
+    else xcur += (sbis > R(0) ? delta : -delta);
+    fcur = f(xcur);
+  }
+  return xcur;
+}
+
+// fixed_depth + general LumpedStorage: residual and derivatives of boundary.py:97-133, :152-164, :213-237.
+// pr: section at hw = z_min + depth (residual), pd: at hw = depth + bed_level (derivatives).
+template <typename R>
+__device__ __noinline__ BCRow<R> bc_storage_curve(const BCDesc<R> bc, int reach, int B, int level, const EntryProps<R> pr,
+                                                  const EntryProps<R> pd, R h, R Q, R Qold, R dt, R Yprev, R *Ynew,
+                                                  int *flag) {
+  StorageCurve<R> sc{bc, reach, B, 0};
+  sc.nc = (int)sc.p(FS_SC_N_CURVE);
+  const R bed = sc.p(FS_SC_BED_LEVEL), ymin = sc.p(FS_SC_MIN_STAGE);
+  R step = R(1);
+  for (int j = 0; j + 1 < sc.nc; ++j) {
+    const R d = fabs_(sc.xs(j + 1) - sc.xs(j));
+    step = j == 0 ? d : (d < step ? d : step);
+  }
+  const R vol = R(0.5) * (Qold + Q) * dt;                               // preissmann.py:314
+  const R Yold = level == 1 ? h + bed : Yprev;                          // boundary.py:104-108 (k==1 quirk)
+  R Y = storage_root(sc, Yold, vol, dt, step, flag);
+  if (Y < ymin) Y = ymin;                                               // lumped_storage.py:32-33
+  *Ynew = Y;
+  const R dY = Y <= ymin ? R(0) : R(1) / sc.area_at(Y);                 // lumped_storage.py:37-45
+  R hl = R(0), dhlA = R(0), dhlQ = R(0);
+  if (sc.p(FS_SC_CAPTURE_LOSSES) > R(0.5)) {                            // lumped_storage.py:47-56, :95-147
+    const R Lr = sc.p(FS_SC_RESERVOIR_LENGTH), Kq = sc.p(FS_SC_K_Q);
+    const R aQ = fabs_(Q);
+    {
+      const R K = conv_(pr.A, pr.neq, pr.Rh), V = Q / pr.A;
+      hl = Q * aQ / (K * K) * Lr + Kq * V * V / (R(2) * R(kG));
+    }
+    const R y13 = pd.Rh > R(0) ? rcbrt_pos(pd.Rh) : R(0);
+    const R R23 = pd.Rh * y13;
+    const R K = pd.A * R23 / pd.neq;
+    const R dK = (R23 + pd.A * R(2.0 / 3.0) * y13 * pd.dRdA) / pd.neq;   // hydraulics.py:28-40
+    const R V = Q / pd.A;
+    dhlA = R(-2) * (Q * aQ / (K * K)) * (dK / K) * Lr + Kq * R(2) * V * (-Q / (pd.A * pd.A)) / (R(2) * R(kG));
+    dhlQ = R(2) * aQ / (K * K) * Lr + Kq * R(2) * V * (R(1) / pd.A) / (R(2) * R(kG));
+  }
+  BCRow<R> r;
+  r.res = h - (Y + hl - bed);
+  r.dh = R(1) - dhlA * pd.dAdh;
+  r.dq = R(0) - (dY * R(0.5) * dt + dhlQ);
+  return r;
+}
+
+template <typename R> __device__ __forceinline__ EntryProps<R> entry_props(const GeneralProps<R> &g) {
+  EntryProps<R> e;
+  e.A = g.A; e.Rh = g.Rh; e.neq = g.neq; e.dRdA = g.dRdA; e.dAdh = g.T;
+  return e;
+}
+
+__host__ __device__ inline bool bc_is_storage(int kind) { return kind == FS_BC_STORAGE || kind == FS_BC_STORAGE_CURVE; }
+
 // sec: section of the boundary node; Qold: flow[k-1] at that node; Yprev: storage stage of level
 // k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).
 template <typename R>
@@ -387,6 +543,11 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
       r.dh = R(1);
       r.dq = R(0) - (Y <= ymin ? R(0) : R(1) / area) * R(0.5) * dt;     // boundary.py:213-237
     } break;
+    case FS_BC_STORAGE_CURVE: {
+      const R bed = p(FS_SC_BED_LEVEL);
+      return bc_storage_curve(bc, reach, B, level, entry_props(general_props_call(sec, h)),
+                              entry_props(general_props_call(sec, h + bed - sec.z)), h, Q, Qold, dt, Yprev, Ynew, flag);
+    }
     default:
       r.res = R(0); r.dh = R(1); r.dq = R(0); break;
   }
@@ -398,7 +559,7 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
 // state around it).  Only the kinds that need no pow() are inlined (bc_is_light): the power rating
 // curve drags ~50 SGPR constants and ~300 instructions of pow() into the hot loop otherwise.
 // zsec = bed level of the boundary node's section.
-__host__ __device__ inline bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER; }
+__host__ __device__ inline bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind != FS_BC_STORAGE_CURVE; }
 
 template <typename R>
 __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach, int B, int level, R b, R n, R zsec,

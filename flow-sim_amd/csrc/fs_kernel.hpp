@@ -227,6 +227,13 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
     if (pn[node] > 0 && bc.kind == FS_BC_NORMAL_DEPTH)
       return bc_normal_depth_poly(poly(node), bc_param(bc, 0, reach, B), bc_param(bc, 1, reach, B), h, Q);
+    if (pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
+      const PolyNode<R> nd = poly(node);
+      const PolyEval<R> er = poly_eval(nd, poly_whole(nd), nd.zmin + h);
+      const PolyEval<R> ed = poly_eval(nd, poly_whole(nd), h + bc_param(bc, FS_SC_BED_LEVEL, reach, B));
+      EntryProps<R> pr{er.A, er.Rh, er.neq, er.dRdA, er.dAdh}, pd{ed.A, ed.Rh, ed.neq, ed.dRdA, ed.dAdh};
+      return bc_storage_curve(bc, reach, B, level, pr, pd, h, Q, Qold, dt, Yprev, Ynew, flag);
+    }
     return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   R *const hk_p = a.hk + base + s0, *const Qk_p = a.Qk + base + s0;
   R *const hg_p = a.hg + base + s0, *const Qg_p = a.Qg + base + s0;
 
-  R Yprev = (a.ds.kind == FS_BC_STORAGE && t == tD) ? a.Yprev[reach] : R(0);
+  R Yprev = (bc_is_storage(a.ds.kind) && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
   int parity = 0;
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
@@ -686,7 +693,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
               a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
             }
           Yprev = Ynew;
-          if (a.ds.kind == FS_BC_STORAGE) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
+          if (bc_is_storage(a.ds.kind)) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
         }
         if (t == tD) {
 #pragma unroll
@@ -711,7 +718,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
     if ((j < M || node == N - 1) && node < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
   }
   if (t == 0) a.status[reach] = status;
-  if (a.ds.kind == FS_BC_STORAGE && t == tD) a.Yprev[reach] = Yprev;
+  if (bc_is_storage(a.ds.kind) && t == tD) a.Yprev[reach] = Yprev;
 #ifdef FS_STAMP
   if (a.dbg && lane == 0)
     for (int i = 0; i < 12; ++i) a.dbg[((size_t)reach * 16 + wave) * 12 + i] = stamp_[i];

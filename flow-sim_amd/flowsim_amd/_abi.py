@@ -18,7 +18,10 @@ GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_comp
             "b_fp_l", "b_fp_r", "m_fp", "curvature")
 GEO_NPARAM = len(GEO_ROWS)
 (BC_FLOW_HYDROGRAPH, BC_STAGE_HYDROGRAPH, BC_FIXED_DEPTH, BC_NORMAL_DEPTH, BC_RATING_POWER,
- BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE) = range(8)
+ BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE, BC_STORAGE_CURVE) = range(9)
+# scalar slots of BC_STORAGE_CURVE (FS_SC_* of the header), followed by stage[n_curve], area[n_curve]
+SC_NAMES = ("min_stage", "Y_min", "Y_max", "bed_level", "surface_area", "alpha", "beta", "n_curve", "rc_type", "rc_a",
+            "rc_b", "rc_c", "rc_shift", "capture_losses", "reservoir_length", "K_q")
 UPSTREAM, DOWNSTREAM = 0, 1
 OK, MAX_ITER, NAN, STORAGE_RANGE = 0, 1, 2, 3
 FLAG_HISTORY, FLAG_TRACE = 1, 2

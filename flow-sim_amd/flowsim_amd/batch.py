@@ -117,6 +117,15 @@ class PreissmannBatch:
             _dptr(ov) if ov is not None else None), "set_geometry_irregular")
 
     def set_boundary(self, side: int, spec: BoundarySpec):
+        if spec.kind == A.BC_STORAGE_CURVE:
+            # general LumpedStorage: the FS_SC_* scalars (missing ones default to 0, alpha to 1) + the area curve
+            curve = np.asarray(spec.params.get("curve", np.empty((0, 2))), dtype=np.float64).reshape(-1, 2)
+            sc = {"alpha": 1.0}
+            sc.update({k: v for k, v in spec.params.items() if k != "curve"})
+            sc["n_curve"] = float(len(curve))
+            p = np.concatenate([[float(sc.get(k) or 0.0) for k in A.SC_NAMES], curve[:, 0], curve[:, 1]])
+            A.check(self._lib.fs_batch_set_bc(self._h, side, spec.kind, _dptr(p), len(p), 0, None), "set_boundary")
+            return
         names = _KIND_PARAMS[spec.kind]
         vals = [np.asarray(spec.params[n], dtype=np.float64) for n in names]
         per_reach = any(v.ndim > 0 for v in vals)

@@ -1,10 +1,12 @@
 """LumpedStorage: 0-D reservoir behind a fixed_depth boundary
 (reference: src/hydromodel/lumped_storage.py:8-179).
 
-The device path covers the configuration the bundled cases use: constant surface area, no
-reservoir rating curve, no entrance losses - there the mass balance root (lumped_storage.py:24-35)
-is Y_new = Y_old + vol_in / area, clamped at min_stage.  Area curves / outflow rating curves /
-entrance losses are SURVEY section 8(f) rank 3 ("next")."""
+Two device forms: the configuration the bundled cases use (constant surface area, no reservoir
+rating curve, no entrance losses), where the mass-balance root (lumped_storage.py:24-35) is
+Y_new = Y_old + vol_in / area clamped at min_stage (FS_BC_STORAGE); and the general one (area
+curve, power / polynomial outflow rating curve, friction + empirical entrance losses), where the
+kernel runs the Brent iteration itself (FS_BC_STORAGE_CURVE).  The expansion loss needs an A_str
+that the reference's Boundary never passes (boundary.py:119-121), so it is always zero there too."""
 import numpy as np
 
 
@@ -48,27 +50,48 @@ class LumpedStorage:
         return 0.5 * (self.area_at(Y2) + self.area_at(Y1)) * (Y2 - Y1)
 
     def energy_loss(self, entry_area, flow, roughness, hydraulic_radius, A_str=None):
+        """Friction over reservoir_length + K_q V^2/2g (+ expansion when A_str is given); lumped_storage.py:47-74."""
         if not self.capture_losses:
             return 0
-        raise NotImplementedError("entrance losses of LumpedStorage are not part of the device path yet")
+        from . import hydraulics
+        V = flow / entry_area
+        hf = hydraulics.Sf(Q=flow, K=hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)) * self.reservoir_length
+        h_exp = 0 if A_str is None else (1 - entry_area / A_str) ** 2 * V ** 2 / (2 * hydraulics.g)
+        return hf + h_exp + self.K_q * V ** 2 / (2 * hydraulics.g)
 
     def mass_balance(self, duration, vol_in, Y_old=None, time=None):
-        """Closed form of the brentq root for the supported configuration."""
-        self._check_supported()
-        Y = Y_old + vol_in / self.surface_area
-        if not (self.Y_min <= Y <= self.Y_max):
-            raise ValueError("f(a) and f(b) must have different signs")
-        return max(Y, self.min_stage)
+        """Stage after taking vol_in over `duration` (lumped_storage.py:24-35), host evaluation for
+        set-up and post-processing; the Newton loop uses the device form."""
+        from scipy.optimize import brentq
 
-    def _check_supported(self):
-        if self.area_curve is not None or self.rating_curve is not None or self.capture_losses:
-            raise NotImplementedError(
-                "device path supports LumpedStorage with constant surface_area, no rating_curve and no "
-                "entrance losses (SURVEY.md 8f rank 3 covers the general case)")
+        def f(Y_new):
+            q_out = 0.5 * (self.rating_curve.discharge(Y_old, time) + self.rating_curve.discharge(Y_new, time)) \
+                if self.rating_curve else 0.0
+            return self.net_vol_change(Y_old, Y_new) - (vol_in - q_out * duration)
+        return max(brentq(f, self.Y_min, self.Y_max), self.min_stage)
+
+    def _is_simple(self):
+        return self.area_curve is None and self.rating_curve is None and not self.capture_losses
 
     def device_spec(self, bed_level):
-        self._check_supported()
-        if self.surface_area is None or self.min_stage is None:
+        if self.min_stage is None or (self.area_curve is None and self.surface_area is None):
             raise ValueError("Insufficient arguments for boundary condition.")
-        return "storage", dict(surface_area=self.surface_area, min_stage=self.min_stage, Y_min=self.Y_min,
-                               Y_max=self.Y_max, bed_level=bed_level)
+        if self._is_simple():
+            return "storage", dict(surface_area=self.surface_area, min_stage=self.min_stage, Y_min=self.Y_min,
+                                   Y_max=self.Y_max, bed_level=bed_level)
+        p = dict(min_stage=self.min_stage, Y_min=self.Y_min, Y_max=self.Y_max, bed_level=bed_level,
+                 surface_area=self.surface_area or 0.0, rc_type=0.0)
+        if self.area_curve is not None:
+            p.update(alpha=self.alpha, beta=self.beta, curve=self.area_curve)
+        rc = self.rating_curve
+        if rc is not None:
+            if getattr(rc, "function", None) is not None or rc.type not in ("power", "polynomial"):
+                raise NotImplementedError("the reservoir rating curve must be RatingCurve.set('power' | 'polynomial', ...) "
+                                          "to run inside the kernel")
+            p.update(rc_type=1.0 if rc.type == "power" else 2.0, rc_a=rc.a, rc_b=rc.b,
+                     rc_c=getattr(rc, "c", 0.0) if rc.type == "polynomial" else 0.0, rc_shift=getattr(rc, "stage_shift", 0.0))
+        if self.capture_losses:
+            if self.reservoir_length is None:
+                raise ValueError("Insufficient arguments for boundary condition.")
+            p.update(capture_losses=1.0, reservoir_length=self.reservoir_length, K_q=self.K_q)
+        return "storage_curve", p

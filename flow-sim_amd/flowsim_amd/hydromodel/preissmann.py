@@ -16,7 +16,7 @@ from . import cross_section as XS
 
 _KIND = {"flow": A.BC_FLOW_HYDROGRAPH, "stage": A.BC_STAGE_HYDROGRAPH, "fixed": A.BC_FIXED_DEPTH,
          "normal": A.BC_NORMAL_DEPTH, "power": A.BC_RATING_POWER, "poly": A.BC_RATING_POLY,
-         "blend": A.BC_RATING_BLEND, "storage": A.BC_STORAGE}
+         "blend": A.BC_RATING_BLEND, "storage": A.BC_STORAGE, "storage_curve": A.BC_STORAGE_CURVE}
 
 
 def boundary_to_spec(boundary, n_levels, dt) -> BoundarySpec:

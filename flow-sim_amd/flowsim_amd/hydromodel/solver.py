@@ -92,8 +92,12 @@ class Solver(ABC):
             self.prepare_results_host()
         st = self.channel.downstream_boundary.lumped_storage
         if st is not None:
-            # level 0 stage = initial interface stage (no entrance losses in the supported configuration)
-            st.stage_hydrograph.insert(0, [0, self.level[0, -1]])
+            # level 0 stage = initial interface stage minus the entrance losses there (solver.py:100-108)
+            Y0 = self.level[0, -1]
+            xs_end = self.channel.xs_at_node[-1]
+            loss0 = st.energy_loss(entry_area=self.area[0, -1], flow=self.flow[0, -1],
+                                   roughness=xs_end.get_equivalent_n(hw=Y0), hydraulic_radius=xs_end.hydraulic_radius(hw=Y0))
+            st.stage_hydrograph.insert(0, [0, Y0 - loss0])
             self.storage_stage = np.array(st.stage_hydrograph, dtype=np.float64)[:, 1].flatten()
             out = np.empty(k + 1)
             out[0] = 0 if st.rating_curve is None else min(self.flow[0, -1], st.rating_curve.discharge(self.storage_stage[0], 0))

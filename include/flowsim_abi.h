@@ -78,9 +78,25 @@ enum {
   FS_BC_RATING_POLY = 5,      /* params: a, b, c, stage_shift, bed_level                      */
   FS_BC_RATING_BLEND = 6,     /* params: stage0, buffer, lo0, lo1, lo2, hi0, hi1, hi2, dY, bed_level
                                  Q = (1-s)*lo(z) + s*hi(z), lo/hi quadratics in z, s = smoothstep */
-  FS_BC_STORAGE = 7           /* params: surface_area, min_stage, Y_min, Y_max, bed_level (downstream only) */
+  FS_BC_STORAGE = 7,          /* params: surface_area, min_stage, Y_min, Y_max, bed_level (downstream only) */
+  FS_BC_STORAGE_CURVE = 8     /* general LumpedStorage (lumped_storage.py:8-179; downstream only): area curve,
+                                 reservoir rating curve, entrance losses.  params[FS_SC_NFIXED + 2*n_curve]:
+                                 the FS_SC_* scalars, then stage[n_curve], area[n_curve] of set_area_curve
+                                 (n_curve = 0: constant surface_area).  The mass-balance root
+                                 (lumped_storage.py:24-35) is found on the device with the algorithm of
+                                 scipy.optimize.brentq and its default tolerances. */
 };
-#define FS_BC_MAX_PARAMS 10
+/* scalar slots of FS_BC_STORAGE_CURVE */
+enum {
+  FS_SC_MIN_STAGE = 0, FS_SC_Y_MIN, FS_SC_Y_MAX, FS_SC_BED_LEVEL, FS_SC_SURFACE_AREA, FS_SC_ALPHA, FS_SC_BETA,
+  FS_SC_N_CURVE,
+  FS_SC_RC_TYPE,            /* 0: no outflow, 1: power a*(Y+shift)^b, 2: polynomial a*x^2 + b*x + c (rating_curve.py:10-63) */
+  FS_SC_RC_A, FS_SC_RC_B, FS_SC_RC_C, FS_SC_RC_SHIFT,
+  FS_SC_CAPTURE_LOSSES,     /* LumpedStorage.capture_losses (0/1) */
+  FS_SC_RESERVOIR_LENGTH, FS_SC_K_Q,
+  FS_SC_NFIXED
+};
+#define FS_BC_MAX_PARAMS 10   /* of the fixed-size kinds 0..7 */
 enum { FS_UPSTREAM = 0, FS_DOWNSTREAM = 1 };
 
 /* per-reach status after stepping (preissmann.py:124-126 raises ValueError; :135-137 NaN check) */

@@ -162,5 +162,47 @@ def irr_mixed():
     return PreissmannSolver(channel=ch, theta=0.65, time_step=300, spatial_step=500, simulation_time=3 * 3600), 1e-6
 
 
-BUILDERS = {"irr_single": irr_single, "irr_levee": irr_levee, "irr_mixed": irr_mixed, "gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
+def _storage_general(rc_type, losses, trap):
+    L = 10000.0
+    hyd = Hydrograph(akbari_shape(200.0, 900.0, 3 * 3600.0, 9 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=2.0, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=5, bed_level=0, chainage=L)
+    stages = np.arange(0.0, 30.01, 0.5)
+    curve = np.column_stack([stages, 2.0e5 + 4.0e4 * stages + 900.0 * stages ** 2])
+    rc = None
+    if rc_type == 'polynomial':
+        rc = RatingCurve(); rc.set(type='polynomial', a=6.0, b=10.0, c=0.0)
+    elif rc_type == 'power':
+        rc = RatingCurve(); rc.set(type='power', a=17.0, b=1.5)
+    ss = LumpedStorage(surface_area=None, min_stage=4.0, solution_boundaries=(0, 30), rating_curve=rc)
+    ss.set_area_curve(curve, alpha=1.1, beta=0.2)
+    if losses:
+        ss.capture_losses = True
+        ss.reservoir_length = 800.0
+        ss.K_q = 0.3
+    ds.set_lumped_storage(ss)
+    if trap:
+        xs_u = TrapezoidalSection(z_bed=2.0, b_main=90.0, m_main=2.0, n_main=0.028, bed_slope=2e-4)
+        xs_d = TrapezoidalSection(z_bed=0.0, b_main=110.0, m_main=2.5, n_main=0.03, bed_slope=2e-4)
+        ch = Channel(initial_flow=200.0, upstream_boundary=us, downstream_boundary=ds)
+        ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    else:
+        ch = Channel(width=100, initial_flow=200.0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds)
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=1200, spatial_step=500, simulation_time=12 * 3600), 1e-6
+
+
+def storage_curve_poly_losses():
+    return _storage_general('polynomial', True, False)
+
+
+def storage_curve_power_trap():
+    return _storage_general('power', True, True)
+
+
+def storage_curve_closed():
+    return _storage_general(None, False, False)
+
+
+BUILDERS = {"storage_curve_poly_losses": storage_curve_poly_losses, "storage_curve_power_trap": storage_curve_power_trap,
+            "storage_curve_closed": storage_curve_closed, "irr_single": irr_single, "irr_levee": irr_levee, "irr_mixed": irr_mixed, "gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
             "bc_compound_normal": bc_compound_normal}

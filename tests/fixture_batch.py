@@ -14,6 +14,19 @@ def boundary_spec(bc: O.BC, nt):
         return BoundarySpec(A.BC_STAGE_HYDROGRAPH, dict(bed_level=bc.bed_level), bc.target)
     if k == "fixed_depth" and bc.storage is None:
         return BoundarySpec(A.BC_FIXED_DEPTH, dict(initial_depth=bc.initial_depth))
+    if k == "fixed_depth" and any(bc.storage.get(x) is not None for x in ("curve", "rc", "losses")):
+        s = bc.storage
+        p = dict(min_stage=s["min_stage"], Y_min=s["Y_min"], Y_max=s["Y_max"], bed_level=bc.bed_level,
+                 surface_area=s.get("area") or 0.0)
+        if s.get("curve") is not None:
+            p.update(curve=s["curve"], alpha=s["alpha"], beta=s["beta"])
+        if s.get("rc") is not None:
+            rc = s["rc"]
+            p.update(rc_type=1.0 if rc["type"] == "power" else 2.0, rc_a=rc["a"], rc_b=rc["b"], rc_c=rc.get("c", 0.0),
+                     rc_shift=rc.get("shift", 0.0))
+        if s.get("losses") is not None:
+            p.update(capture_losses=1.0, reservoir_length=s["losses"]["reservoir_length"], K_q=s["losses"]["K_q"])
+        return BoundarySpec(A.BC_STORAGE_CURVE, p)
     if k == "fixed_depth":
         s = bc.storage
         return BoundarySpec(A.BC_STORAGE, dict(surface_area=s["area"], min_stage=s["min_stage"], Y_min=s["Y_min"],
@@ -39,6 +52,9 @@ def merge_specs(specs, B):
     """Per-reach parameter arrays from a list of B single-reach specs of the same kind."""
     kind = specs[0].kind
     assert all(s.kind == kind for s in specs)
+    if kind == A.BC_STORAGE_CURVE:
+        assert B == 1, "general storage parameters are shared by the batch"
+        return specs[0]
     params = {k: np.array([s.params[k] for s in specs], dtype=np.float64) for k in specs[0].params}
     tgt = None
     if specs[0].target is not None:

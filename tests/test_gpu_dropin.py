@@ -81,7 +81,8 @@ def test_manning_ensemble_batch_matches_sequential_reference_runs():
         assert np.array_equal(res["iterations"][:, i], fx["iters"][i])
 
 
-@pytest.mark.parametrize("name", ["akbari", "example", "bc_compound_normal", "gerd", "irr_levee", "irr_mixed"])
+@pytest.mark.parametrize("name", ["akbari", "example", "bc_compound_normal", "gerd", "irr_levee", "irr_mixed",
+                                  "storage_curve_poly_losses", "storage_curve_power_trap", "storage_curve_closed"])
 def test_derived_fields_kernel_matches_reference_post_processing(name):
     """fs_batch_derive (HIP, elementwise) vs the reference's Solver.prepare_results output."""
     fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
