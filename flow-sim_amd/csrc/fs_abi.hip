@@ -73,7 +73,8 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),
+                          FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1)};
 #else
 const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_IRREGULAR};
 #endif
@@ -177,7 +178,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   fs::BCDesc<R> *bc[2] = {&a.us, &a.ds};
   for (int s = 0; s < 2; ++s) {
     bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
-    bc[s]->params = (const R *)b->bc_params[s]; bc[s]->target = (const R *)b->bc_target[s];
+    bc[s]->params = (const R *)b->bc_params[s]; bc[s]->target = (const R *)b->bc_target[s]; bc[s]->tgt = R(0);
   }
   a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.trace = (R *)b->trace; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;

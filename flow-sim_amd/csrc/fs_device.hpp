@@ -311,6 +311,7 @@ template <typename R> struct BCDesc {
   int32_t stride;          // 0: params shared by all reaches, 1: params[i*B + reach]
   const R *params;
   const R *target;         // [levels][B] or nullptr
+  R tgt;                   // device side: target[level][reach] of the level being solved (loaded once per level)
 };
 template <typename R> struct BCRow { R dh, dq, res; };   // dh*d(h) + dq*d(Q) = -res
 
@@ -495,9 +496,9 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
   auto p = [&](int i) { return bc_param(bc, i, reach, B); };
   switch (bc.kind) {
     case FS_BC_FLOW_HYDROGRAPH:
-      r.res = Q - bc.target[(size_t)level * B + reach]; r.dh = R(0); r.dq = R(1); break;
+      r.res = Q - bc.tgt; r.dh = R(0); r.dq = R(1); break;
     case FS_BC_STAGE_HYDROGRAPH:
-      r.res = h - (bc.target[(size_t)level * B + reach] - p(0)); r.dh = R(1); r.dq = R(0); break;
+      r.res = h - (bc.tgt - p(0)); r.dh = R(1); r.dq = R(0); break;
     case FS_BC_FIXED_DEPTH:
       r.res = h - p(0); r.dh = R(1); r.dq = R(0); break;
     case FS_BC_NORMAL_DEPTH: {
@@ -568,9 +569,9 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach,
   auto p = [&](int i) { return bc_param(bc, i, reach, B); };
   switch (bc.kind) {
     case FS_BC_FLOW_HYDROGRAPH:
-      r.res = Q - bc.target[(size_t)level * B + reach]; r.dh = R(0); r.dq = R(1); break;
+      r.res = Q - bc.tgt; r.dh = R(0); r.dq = R(1); break;
     case FS_BC_STAGE_HYDROGRAPH:
-      r.res = h - (bc.target[(size_t)level * B + reach] - p(0)); r.dh = R(1); r.dq = R(0); break;
+      r.res = h - (bc.tgt - p(0)); r.dh = R(1); r.dq = R(0); break;
     case FS_BC_FIXED_DEPTH:
       r.res = h - p(0); r.dh = R(1); r.dq = R(0); break;
     case FS_BC_NORMAL_DEPTH: {

@@ -42,6 +42,12 @@
 #ifndef FS_LEVEL_FENCE
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
+#ifndef FS_PIN_SEG
+#define FS_PIN_SEG 1     // 1: keep each merge in its cell region (+3%), 2: additionally skewed by one cell (no further gain)
+#endif
+#ifndef FS_LDS_FIRST
+#define FS_LDS_FIRST 0
+#endif
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
@@ -249,6 +255,7 @@ template <typename R, int M, int W> struct Smem {
   R tree[W][10][TreeCfg<W>::kSlots];   // per-wave spill slots of the in-wave tree
   R xseg[2][W][10];        // wave segments, double-buffered by iteration parity
   R xbc[2][8];             // boundary rows: U(dh,dq,res) D(dh,dq,res)
+  R bcp[2][FS_BC_MAX_PARAMS];   // this reach's boundary parameters (fixed-size kinds), read every Newton iteration
   R xnorm[2][W];
   int32_t xflag[2];
 };
@@ -323,6 +330,20 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   R *const hk_p = a.hk + base + s0, *const Qk_p = a.Qk + base + s0;
   R *const hg_p = a.hg + base + s0, *const Qg_p = a.Qg + base + s0;
 
+  // Boundary descriptors of this reach: the parameters of the fixed-size kinds are copied to LDS once
+  // (the boundary rows are evaluated every Newton iteration on the critical path of the first and the
+  // last wave; a global load there costs more than the row itself), the hydrograph value of a level
+  // is fetched when the level starts.
+  BCDesc<R> usd = a.us, dsd = a.ds;
+  if (t < 2 * FS_BC_MAX_PARAMS) {
+    const int side = t / FS_BC_MAX_PARAMS, i = t - side * FS_BC_MAX_PARAMS;
+    const BCDesc<R> &src = side ? a.ds : a.us;
+    static constexpr int kCount[] = {0, 1, 1, 2, 4, 5, 10, 5};
+    if (src.kind <= FS_BC_STORAGE && i < kCount[src.kind]) sm.bcp[side][i] = bc_param(src, i, reach, a.B);
+  }
+  if (usd.kind <= FS_BC_STORAGE) { usd.params = &sm.bcp[0][0]; usd.stride = 0; }
+  if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
+
   R Yprev = (bc_is_storage(a.ds.kind) && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
   int parity = 0;
@@ -348,6 +369,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
 #endif
   for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
     const int level = a.level0 + step + 1;
+    if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
+    if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
     int it = 0;
     bool converged = false;
     R Ynew = Yprev;
@@ -437,11 +460,44 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
       Seg<R> seg;
       R nrm2 = R(0);
+      // merge(sg, cell) keeping only what the local back-substitution reads
+      auto fold_merge = [&](Seg<R> &sg, const Seg<R> &cell, LocalElim<R> &e) {
+        const R det = sg.sm0 * cell.pc1 - sg.sm1 * cell.pc0;
+        const R r = frcp(det);
+        e.rs0.put(r * sg.sm0); e.rs1.put(r * sg.sm1); e.rp0.put(r * sg.pm0); e.rp1.put(r * sg.pm1);
+        e.rq.put(r * sg.qm);
+        if (!Geo::kConstT) e.qc.put(cell.qc);
+        const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -sg.sm1 * r, w21 = sg.sm0 * r;
+        const R al = sg.sc0 * w10 + sg.sc1 * w11, be = sg.sc0 * w20 + sg.sc1 * w21;
+        const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
+        Seg<R> o;
+        o.pc0 = sg.pc0 - al * sg.pm0; o.pc1 = sg.pc1 - al * sg.pm1;
+        o.sc0 = -be * cell.sc0;         o.sc1 = -be * cell.sc1;
+        o.qc = sg.qc - al * sg.qm - be * cell.qc;
+        o.pm0 = -ga * sg.pm0;          o.pm1 = -ga * sg.pm1;
+        o.sm0 = cell.sm0 - ep * cell.sc0; o.sm1 = cell.sm1 - ep * cell.sc1;
+        o.qm = cell.qm - ga * sg.qm - ep * cell.qc;
+        sg = o;
+      };
       {
         NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
         if (!Geo::kConstT) Tn[0] = L.T;
+        Seg<R> prev;
+#if FS_LDS_FIRST
+        R kn0 = kcb[(0 * M) * T], kn1 = kcb[(1 * M) * T], kn2 = kcb[(2 * M) * T], kn3 = kcb[(3 * M) * T];
+#endif
 #pragma unroll
         for (int c = 0; c < M; ++c) {
+#if FS_LDS_FIRST
+          // level constants one cell ahead: requested in this scheduling region, consumed in the next
+          const R k0 = kn0, k1 = kn1, k2 = kn2, k3 = kn3;
+          if (c + 1 < M) {
+            kn0 = kcb[(0 * M + c + 1) * T]; kn1 = kcb[(1 * M + c + 1) * T];
+            kn2 = kcb[(2 * M + c + 1) * T]; kn3 = kcb[(3 * M + c + 1) * T];
+          }
+#else
+          const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
+#endif
           const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
           if (!Geo::kConstT) Tn[c + 1] = Rn.T;
           Seg<R> cell;
@@ -449,10 +505,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
             // identity padding d_{i+1} = d_i beyond the last cell
             const bool real = (RAGGED || c == M - 1) ? (s0 + c < NC) : true;
             const R sumA = L.A + Rn.A;
-            const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + kcb[(0 * M + c) * T];          // :220-249
-            const R avgA = hth * sumA + kcb[(2 * M + c) * T];
-            const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + kcb[(3 * M + c) * T];
-            const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + kcb[(1 * M + c) * T] +
+            const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + k0;                            // :220-249
+            const R avgA = hth * sumA + k2;
+            const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + k3;
+            const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + k1 +
                            g * avgA * S;                                                     // :251-301
             nrm2 += real ? Cres * Cres + Mres * Mres : R(0);
             const R gA = g * avgA, gS = g * hth * S;
@@ -465,6 +521,18 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
             cell.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
             cell.qm = real ? -Mres : R(0);
           }
+#if FS_PIN_SEG == 2
+          // software pipeline by one cell: this region merges cell c-1 (a serial chain) next to the
+          // independent assembly of cell c
+          if (c == 1) {
+            seg = prev;
+          } else if (c >= 2) {
+            fold_merge(seg, prev, el[c - 2]);
+          }
+          prev = cell;
+          asm volatile("" :: "v"(prev.pc0), "v"(prev.sc0), "v"(prev.qc), "v"(prev.pm0), "v"(prev.pm1), "v"(prev.sm0),
+                             "v"(prev.sm1), "v"(prev.qm));
+#else
           if (c == 0) {
             seg = cell;
           } else {
@@ -487,11 +555,24 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
             o.qm = cell.qm - ga * seg.qm - ep * cell.qc;
             seg = o;
           }
+#endif
+#if FS_PIN_SEG
+          // the running segment must exist here: keeps cell c's merge inside cell c's scheduling region
+          // (otherwise the 15 merges sink below the last fence and every cell's coefficients are parked)
+          // (long chunks only: with M <= 4 the cells' node terms interleave profitably, measured on C4)
+          if (M >= 8 && (FS_PIN_SEG == 1 || c >= 1))
+            asm volatile("" :: "v"(seg.pc0), "v"(seg.pc1), "v"(seg.sc0), "v"(seg.sc1), "v"(seg.qc),
+                               "v"(seg.pm0), "v"(seg.pm1), "v"(seg.sm0), "v"(seg.sm1), "v"(seg.qm));
+#endif
           L = Rn;
 #if FS_CELL_FENCE
           if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
+#if FS_PIN_SEG == 2
+        if (M == 1) seg = prev;
+        else fold_merge(seg, prev, el[M - 2]);
+#endif
       }
 
 #endif
@@ -499,7 +580,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
-        const BCRow<R> U = geo.template boundary<BCFAST>(a.us, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        const BCRow<R> U = geo.template boundary<BCFAST>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
         sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
         nrm2 += U.res * U.res;
       }
@@ -508,7 +589,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         int flag = 0;
 #pragma unroll
         for (int j = 1; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        const BCRow<R> Dn = geo.template boundary<BCFAST>(a.ds, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        const BCRow<R> Dn = geo.template boundary<BCFAST>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
         nrm2 += Dn.res * Dn.res;
         if (flag) sm.xflag[parity] = flag;

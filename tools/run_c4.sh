@@ -1,6 +1,5 @@
-for v in flow-sim_amd/csrc/variants/lib_g*.so; do
-  for shape in "2,1" "4,1"; do
-  echo -n "$(basename $v) shape $shape "
-  FS_KERNEL_SHAPE=$shape FS_LIB=$PWD/$v timeout -k 10 300 python bench.py --workload c4 --reaches 32768 --steps 16 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(f\"{d['value']:.4g} r-ts/s  kernel_ms {d['roofline']['kernel_ms']:.2f} {d['config']['kernel']} conv {d['config']['all_converged']}\")"
-  done
+# C4 (gerd_roseires Manning-n ensemble) on every variant library under flow-sim_amd/csrc/variants
+for v in flow-sim_amd/csrc/variants/lib_*.so; do
+  echo -n "$(basename $v) "
+  FS_LIB=$PWD/$v timeout -k 10 300 python bench.py --workload c4 --reaches 32768 --steps 16 --warmup 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(f\"{d['value']:.4g} r-ts/s  kernel_ms {d['roofline']['kernel_ms']:.2f} {d['config']['kernel']} conv {d['config']['all_converged']}\")"
 done
