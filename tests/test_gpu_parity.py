@@ -217,6 +217,54 @@ def test_max_iter_and_status_reporting():
         assert b.iterations()[1, 0] == 1
 
 
+@pytest.mark.parametrize("N", [2, 3, 5, 64, 65, 66, 129, 513, 1025, 2049, 4097])
+def test_ragged_node_counts_against_the_c_oracle(N):
+    """Smallest (one cell), off-by-one around every lane / wave capacity and the largest supported
+    reach (4097 nodes): padding cells, the last-lane bookkeeping and the cross-wave fold."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle
+    from synth import rect_problem
+    probs = [rect_problem(N, seed=100 + N + s, n_steps=3) for s in range(2)]
+    with batch_from_problems(probs) as b:
+        b.step(3)
+        assert np.all(b.status() == 0)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    for i, p in enumerate(probs):
+        out = c_oracle.run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL, N
+        assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL, N
+        assert np.array_equal(its[:, i], out["iters"]), N
+
+
+def test_failing_reach_does_not_disturb_its_neighbours():
+    """One reach of a batch runs out of Newton iterations (its inflow jumps by three orders of
+    magnitude); the others finish, bit-identical to a batch without it, and each status is its own."""
+    from fixture_batch import batch_from_problems
+    from synth import rect_problem
+    probs = [rect_problem(300, seed=40 + s, n_steps=4) for s in range(4)]
+    bad = rect_problem(300, seed=44, n_steps=4)
+    bad.us.target = bad.us.target.copy()
+    bad.us.target[2:] *= -5.0e3                      # flow reversal far beyond the channel: no convergence
+    bad.max_iter = probs[0].max_iter = 12
+    for p in probs:
+        p.max_iter = 12
+    with batch_from_problems(probs) as b:
+        b.step(4)
+        ref_h, ref_Q = b.history_arrays()
+        assert np.all(b.status() == 0)
+    mixed = probs[:2] + [bad] + probs[2:]
+    with batch_from_problems(mixed) as b:
+        b.step(4)
+        st = b.status()
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    assert st[2] != 0 and np.all(np.delete(st, 2) == 0), st
+    keep = [0, 1, 3, 4]
+    assert np.array_equal(h[:, keep], ref_h) and np.array_equal(Q[:, keep], ref_Q)
+    assert its[1, 2] > 0 and np.all(its[3:, 2] == 0)      # the failing reach stopped at the level that failed
+
+
 # ---------------------------------------------------------------------------------------------
 # uniform trapezoid mode (BASELINE configs[4] geometry) and fp32
 # ---------------------------------------------------------------------------------------------
