@@ -562,11 +562,13 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
 // zsec = bed level of the boundary node's section.
 __host__ __device__ inline bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind != FS_BC_STORAGE_CURVE; }
 
+// lp: this reach's parameters in LDS (typed pointer: ds_read, not a flat load through a generic one)
+template <typename R> using LdsParams = const __attribute__((address_space(3))) R *;
 template <typename R>
-__device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach, int B, int level, R b, R n, R zsec,
+__device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<R> lp, int level, R b, R n, R zsec,
                                                  R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
   BCRow<R> r;
-  auto p = [&](int i) { return bc_param(bc, i, reach, B); };
+  auto p = [&](int i) { return lp[i]; };
   switch (bc.kind) {
     case FS_BC_FLOW_HYDROGRAPH:
       r.res = Q - bc.tgt; r.dh = R(0); r.dq = R(1); break;
@@ -575,21 +577,30 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, int reach,
     case FS_BC_FIXED_DEPTH:
       r.res = h - p(0); r.dh = R(1); r.dq = R(0); break;
     case FS_BC_NORMAL_DEPTH: {
-      const R S0 = p(0), bed = p(1);
-      const R sg = S0 < R(0) ? R(-1) : R(1);
-      const R rt = sqrt_(fabs_(S0));
-      // K = A R^(2/3) / n ; dK/dA * T = K (1 + (2/3) b/P) / h        (rectangle)
-      const R P = __builtin_fma(R(2), h, b);
-      const R Rh = b * h * frcp(P);
+      // p(2) = sign(S0) sqrt|S0|, prepared once per launch next to the cached parameters (fs_kernel.hpp)
+      const R bed = p(1), srt = p(2);
       const R rn = frcp(n);
-      const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
+      // K = A R^(2/3) / n ; dK/dA * T = K (1 + (2/3) b/P) / h        (rectangle)
       const R hd = h + bed - zsec;                                      // df_dh uses hw = h + bed_level
-      const R Pd = __builtin_fma(R(2), hd, b);
-      const R rPd = frcp(Pd);
-      const R Rd = b * hd * rPd;
-      const R Kd = b * hd * Rd * rcbrt_pos(Rd) * rn;
-      r.res = Q - sg * K * rt;
-      r.dh = R(0) - sg * rt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) * frcp(hd);
+      const R P = __builtin_fma(R(2), h, b);
+      if (hd == h) {
+        // the usual case (boundary bed level == section bed): one reciprocal serves both evaluations,
+        // 1/h = P/(P h) and b/P = b h/(P h)
+        const R q = frcp(P * h);
+        const R Rh = b * h * h * q;
+        const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
+        r.res = Q - srt * K;
+        r.dh = R(0) - srt * K * __builtin_fma(R(2.0 / 3.0) * b * h, q, R(1)) * (P * q);
+      } else {
+        const R Rh = b * h * frcp(P);
+        const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
+        const R Pd = __builtin_fma(R(2), hd, b);
+        const R rPd = frcp(Pd);
+        const R Rd = b * hd * rPd;
+        const R Kd = b * hd * Rd * rcbrt_pos(Rd) * rn;
+        r.res = Q - srt * K;
+        r.dh = R(0) - srt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) * frcp(hd);
+      }
       r.dq = R(1);
     } break;
     case FS_BC_RATING_POLY: {
@@ -721,12 +732,45 @@ template <int D, typename R> __device__ __forceinline__ R tree_from_below(R v) {
   return __shfl_up(v, D, 64);
 #endif
 }
+// gfx950 lane-permute swaps: second result of v_permlane16_swap / v_permlane32_swap with both operands = v,
+// i.e. rows 0/2 receive rows 1/3 (16) or the lower half receives the upper half (32)
+__device__ __forceinline__ int swap16_(int v) { return (int)__builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false)[1]; }
+__device__ __forceinline__ int swap32_(int v) { return (int)__builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false)[1]; }
+__device__ __forceinline__ double swap16_(double v) { return __hiloint2double(swap16_(__double2hiint(v)), swap16_(__double2loint(v))); }
+__device__ __forceinline__ double swap32_(double v) { return __hiloint2double(swap32_(__double2hiint(v)), swap32_(__double2loint(v))); }
+__device__ __forceinline__ float swap16_(float v) { return __int_as_float(swap16_(__float_as_int(v))); }
+__device__ __forceinline__ float swap32_(float v) { return __int_as_float(swap32_(__float_as_int(v))); }
+
 // value of lane + D for lanes with (lane & (2D-1)) == D-1 (others: unspecified)
 template <int D, typename R> __device__ __forceinline__ R tree_from_above(R v) {
 #if FS_DPP
   if (D < 16) return dpp_mov<0x100 + (D < 16 ? D : 1)>(v);      // row_shl:D
-#endif
+  if (D == 16) return swap16_(v);                                 // lanes 15, 47 <- lanes 31, 63
+  return swap32_(v);                                              // lane 31 <- lane 63
+#else
   return __shfl_down(v, D, 64);
+#endif
+}
+// value of lane - D2 for lanes with (lane & (D2-1)) == D2-1 and lane >= D2 (others: unspecified)
+template <int D2, typename R> __device__ __forceinline__ R fetch_left(R v, int lane) {
+#if FS_DPP
+  if (D2 >= 64) return v;
+  if (D2 == 32) return dpp_mov<0x143>(v);                         // row_bcast31: lane 63 <- lane 31
+  const R up = dpp_mov<0x142>(v);                                 // row_bcast15: every row <- lane 15 of the row before
+  if (D2 == 16) return up;
+  const R in_row = dpp_mov<0x110 + (D2 < 16 ? D2 : 1)>(v);        // row_shr:D2
+  return (lane & 15) == D2 - 1 ? up : in_row;                     // the first candidate of a row reaches into the row before
+#else
+  return __shfl_up(v, D2, 64);
+#endif
+}
+// value of lane - 1 (lane 0: unspecified)
+template <typename R> __device__ __forceinline__ R wave_shr1(R v) {
+#if FS_DPP
+  return dpp_mov<0x138>(v);                                       // wave_shr:1
+#else
+  return __shfl_up(v, 1, 64);
+#endif
 }
 
 template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(const Seg<R> &s) {
@@ -737,10 +781,36 @@ template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(co
   o.qm = tree_from_below<D>(s.qm);
   return o;
 }
+template <int CTRL, int ROWS, int BANKS> __device__ __forceinline__ int dpp_zero(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, BANKS, true);     // lanes without a source (or masked off) get 0
+}
+template <int CTRL, int ROWS, int BANKS> __device__ __forceinline__ double dpp_zero(double v) {
+  return __hiloint2double(dpp_zero<CTRL, ROWS, BANKS>(__double2hiint(v)), dpp_zero<CTRL, ROWS, BANKS>(__double2loint(v)));
+}
+template <int CTRL, int ROWS, int BANKS> __device__ __forceinline__ float dpp_zero(float v) {
+  return __int_as_float(dpp_zero<CTRL, ROWS, BANKS>(__float_as_int(v)));
+}
+// sum over the 64 lanes, the same value in every lane (fixed order: prefix sums inside each row of 16,
+// then across rows; lane 63 holds the total and is broadcast through a scalar register)
 template <typename R> __device__ __forceinline__ R wave_sum(R v) {
+#if FS_DPP
+  v += dpp_zero<0x111, 0xF, 0xF>(v);        // row_shr:1
+  v += dpp_zero<0x112, 0xF, 0xF>(v);        // row_shr:2
+  v += dpp_zero<0x114, 0xF, 0xF>(v);        // row_shr:4
+  v += dpp_zero<0x118, 0xF, 0xF>(v);        // row_shr:8   -> lane 15 of a row: the row's sum
+  v += dpp_zero<0x142, 0xA, 0xF>(v);        // row_bcast15 into rows 1 and 3
+  v += dpp_zero<0x143, 0xC, 0xF>(v);        // row_bcast31 into rows 2 and 3 -> lane 63: total
+  if constexpr (sizeof(R) == 8) {
+    const double d = v;
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(d), 63), __builtin_amdgcn_readlane(__double2loint(d), 63));
+  } else {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+  }
+#else
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
+#endif
 }
 
 }  // namespace fs

@@ -120,8 +120,8 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   template <bool BCFAST>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    if (BCFAST)
-      return bc_eval_rect(bc, reach, B, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
+    if (BCFAST)   // bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only)
+      return bc_eval_rect(bc, (LdsParams<R>)bc.params, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
     return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
@@ -279,6 +279,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   const int s0 = t * M;                       // first node / cell of this lane
   const int tD = (NC - 1) / M;                // lane that owns the last real cell
   const int jD = NC - tD * M;                 // local index (1..M) of node N-1 in that lane
+  constexpr int kJD0 = RAGGED ? 1 : (M > 1 ? M - 1 : 1);   // full chunks: jD is M-1 or M
   const size_t base = (size_t)reach * N;
 
   Geo geo;
@@ -340,6 +341,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
     const BCDesc<R> &src = side ? a.ds : a.us;
     static constexpr int kCount[] = {0, 1, 1, 2, 4, 5, 10, 5};
     if (src.kind <= FS_BC_STORAGE && i < kCount[src.kind]) sm.bcp[side][i] = bc_param(src, i, reach, a.B);
+    if (src.kind == FS_BC_NORMAL_DEPTH && i == 2) {        // derived: sign(S0) sqrt|S0| (hydraulics.py:4-13)
+      const R S0 = bc_param(src, 0, reach, a.B);
+      sm.bcp[side][2] = (S0 < R(0) ? R(-1) : R(1)) * sqrt_(fabs_(S0));
+    }
   }
   if (usd.kind <= FS_BC_STORAGE) { usd.params = &sm.bcp[0][0]; usd.stride = 0; }
   if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
     }
     if (t == tD) {
 #pragma unroll
-      for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Qk[j];
+      for (int j = kJD0; j <= M; ++j) if (j == jD) QoldD = Qk[j];
     }
     write_level_constants(hk, Qk);
   }
@@ -588,7 +593,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         R hD = h[0], QD = Q[0];
         int flag = 0;
 #pragma unroll
-        for (int j = 1; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+        for (int j = kJD0; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
         const BCRow<R> Dn = geo.template boundary<BCFAST>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
         nrm2 += Dn.res * Dn.res;
@@ -676,8 +681,8 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         constexpr int l = decltype(lc)::value;
         constexpr int d = 1 << l;
         // left end of the merged pair: lane - 2d (a lane with all low bits set), or the wave's left boundary
-        // (lane - 2d can sit in the previous DPP row, so this one fetch stays a ds_bpermute)
-        R e0 = shfl_up_(dR0, 2 * d), e1 = shfl_up_(dR1, 2 * d);
+        // (row_shr inside a DPP row, row_bcast15/31 when lane - 2d sits in the row before: no LDS round trip)
+        R e0 = fetch_left<2 * d>(dR0, lane), e1 = fetch_left<2 * d>(dR1, lane);
         if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
         R m0 = R(0), m1 = R(0);
         if ((lane & (2 * d - 1)) == (2 * d - 1)) {
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       down_level(std::integral_constant<int, 5>{}); down_level(std::integral_constant<int, 4>{});
       down_level(std::integral_constant<int, 3>{}); down_level(std::integral_constant<int, 2>{});
       down_level(std::integral_constant<int, 1>{}); down_level(std::integral_constant<int, 0>{});
-      R dL0 = shfl_up_(dR0, 1), dL1 = shfl_up_(dR1, 1);
+      R dL0 = wave_shr1(dR0), dL1 = wave_shr1(dR1);
       if (lane == 0) { dL0 = bL0; dL1 = bL1; }
 
       // The update is kept pending in dh/dQ (they take the registers the elimination records free up):
@@ -768,7 +773,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         FS_T(8);
         if (t == tD) {
 #pragma unroll
-          for (int j = 1; j <= M; ++j)
+          for (int j = kJD0; j <= M; ++j)
             if (j == jD) {
               a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
               a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         }
         if (t == tD) {
 #pragma unroll
-          for (int j = 1; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
+          for (int j = kJD0; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
         }
         FS_T(9);
         write_level_constants(h, Q);                                  // level constants of the next level
