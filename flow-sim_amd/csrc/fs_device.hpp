@@ -41,17 +41,15 @@ __device__ __forceinline__ float frcp(float x) {
   return __builtin_fmaf(r, e, r);
 }
 
-// x^(-1/3) for x > 0
+// x^(-1/3) for x > 0: single-precision log2/exp2 seed y (relative error ~1e-7, so e = 1 - x y^3 ~ 3e-7),
+// then ONE third-order correction y (1 - e)^(-1/3) = y (1 + e/3 + 2 e^2/9 + O(e^3)): the neglected term is
+// ~ (14/81) e^3 < 1e-19, below double rounding (two plain Newton steps cost four more instructions)
 __device__ __forceinline__ double rcbrt_pos(double x) {
-  float xf = (float)x;
-  double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {  // Newton on y^-3 = x : y += y*(1 - x y^3)/3
-    double t = y * y;
-    double e = __builtin_fma(-(x * t), y, 1.0);
-    y = __builtin_fma(y * (1.0 / 3.0), e, y);
-  }
-  return y;
+  const float xf = (float)x;
+  const double y = (double)__builtin_amdgcn_exp2f(__builtin_amdgcn_logf(xf) * (-1.0f / 3.0f));
+  const double e = __builtin_fma(-(x * (y * y)), y, 1.0);
+  const double p = __builtin_fma(e, 2.0 / 9.0, 1.0 / 3.0);
+  return __builtin_fma(y * e, p, y);
 }
 __device__ __forceinline__ float rcbrt_pos(float x) {
   float y = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * (-1.0f / 3.0f));
@@ -712,8 +710,13 @@ template <typename R> __device__ __forceinline__ R shfl_(R v, int l) { return __
 #ifndef FS_DPP
 #define FS_DPP 1
 #endif
+#ifndef FS_DPP_TIED
+#define FS_DPP_TIED 1   // 1: dst tied to the source (copy + in-place DPP); 0: bound_ctrl, no copy - faster in isolation, slower inside the kernel
+#endif
+// lanes without a source read 0 (bound_ctrl): their value is unspecified for every caller below, and an
+// "old" operand that never shows through spares the register copy that keeps v alive next to its shifted copy
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+  return FS_DPP_TIED ? __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
   const int lo = dpp_mov<CTRL>(__double2loint(v)), hi = dpp_mov<CTRL>(__double2hiint(v));

@@ -389,6 +389,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       // constants are Newton-loop invariants and would otherwise be hoisted into registers
       int kco = t;
       asm volatile("" : "+v"(kco));
+      // the same for the lane number the tree-slot addresses derive from: as loop invariants the 12 addresses
+      // are hoisted and spilled to scratch, and every reload is a full memory round trip inside the tree
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
       const R *kcb = &sm.kc[0][0][0] + kco;
 
 #if FS_SKEW
@@ -615,13 +619,13 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           if (L0R && l == 0) {
             e_l0 = e;
           } else {
-            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (lane >> (l + 1));
+            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
             R *p = &sm.tree[wave][0][slot];
             p[0 * TS] = e.w10; p[1 * TS] = e.w11; p[2 * TS] = e.w20; p[3 * TS] = e.w21; p[4 * TS] = e.pm0;
             p[5 * TS] = e.pm1; p[6 * TS] = e.qm;  p[7 * TS] = e.sc0; p[8 * TS] = e.sc1; p[9 * TS] = e.qc;
           }
-          seg = mg;
         }
+        seg = mg;      // in every lane: a lane that does not survive this level is not read again (no select, no branch around the merge)
       };
       up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
       up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
@@ -641,26 +645,31 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       R tot = R(0);
       R bL0, bL1, bR0, bR1;          // updates at the first / last node of this wave's span
       {
-        Seg<R> acc;
+        // pairwise tree over the W wave segments (depth log2 W instead of a serial chain of W-1 merges;
+        // the two merges of a level are independent and overlap)
+        Seg<R> sw[W];
         Elim<R> we[W > 1 ? W - 1 : 1];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           const R *p = sm.xseg[parity][w];
-          Seg<R> sw;
-          sw.pc0 = p[0]; sw.pc1 = p[1]; sw.sc0 = p[2]; sw.sc1 = p[3]; sw.qc = p[4];
-          sw.pm0 = p[5]; sw.pm1 = p[6]; sw.sm0 = p[7]; sw.sm1 = p[8]; sw.qm = p[9];
+          sw[w].pc0 = p[0]; sw[w].pc1 = p[1]; sw[w].sc0 = p[2]; sw[w].sc1 = p[3]; sw[w].qc = p[4];
+          sw[w].pm0 = p[5]; sw[w].pm1 = p[6]; sw[w].sm0 = p[7]; sw[w].sm1 = p[8]; sw[w].qm = p[9];
           tot += sm.xnorm[parity][w];
-          if (w == 0) acc = sw;
-          else merge(acc, sw, acc, we[w - 1]);
         }
+#pragma unroll
+        for (int st = 1; st < W; st *= 2)
+#pragma unroll
+          for (int i = 0; i + st < W; i += 2 * st) merge(sw[i], sw[i + st], sw[i], we[i + st - 1]);
         BCRow<R> U, Dn;
         U.dh = sm.xbc[parity][0]; U.dq = sm.xbc[parity][1]; U.res = sm.xbc[parity][2];
         Dn.dh = sm.xbc[parity][3]; Dn.dq = sm.xbc[parity][4]; Dn.res = sm.xbc[parity][5];
         R bnd[W + 1][2];
-        close_system(acc, U, Dn, bnd[0][0], bnd[0][1], bnd[W][0], bnd[W][1]);
+        close_system(sw[0], U, Dn, bnd[0][0], bnd[0][1], bnd[W][0], bnd[W][1]);
 #pragma unroll
-        for (int w = W - 1; w >= 1; --w)
-          back(we[w - 1], bnd[0][0], bnd[0][1], bnd[w + 1][0], bnd[w + 1][1], bnd[w][0], bnd[w][1]);
+        for (int st = W / 2; st >= 1; st /= 2)
+#pragma unroll
+          for (int i = 0; i + st < W; i += 2 * st)
+            back(we[i + st - 1], bnd[i][0], bnd[i][1], bnd[i + 2 * st][0], bnd[i + 2 * st][1], bnd[i + st][0], bnd[i + st][1]);
         bL0 = bnd[0][0]; bL1 = bnd[0][1]; bR0 = bnd[1][0]; bR1 = bnd[1][1];
 #pragma unroll
         for (int w = 1; w < W; ++w)
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           if (L0R && l == 0) {
             e = e_l0;
           } else {
-            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (lane >> (l + 1));
+            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
             const R *p = &sm.tree[wave][0][slot];
             e.w10 = p[0 * TS]; e.w11 = p[1 * TS]; e.w20 = p[2 * TS]; e.w21 = p[3 * TS]; e.pm0 = p[4 * TS];
             e.pm1 = p[5 * TS]; e.qm = p[6 * TS];  e.sc0 = p[7 * TS]; e.sc1 = p[8 * TS]; e.qc = p[9 * TS];

@@ -13,6 +13,9 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
   const Seg<double> left = seg_from_below<d>(seg);
   Seg<double> mg; Elim<double> e;
   merge(left, seg, mg, e);
+#if VARIANT == 2
+  seg = mg;       // every lane: the lanes that do not survive this level are never read again
+#endif
   if ((lane & (2 * d - 1)) == (2 * d - 1)) {
 #if VARIANT != 1
     const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
@@ -20,7 +23,9 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
     p[0 * 64] = e.w10; p[1 * 64] = e.w11; p[2 * 64] = e.w20; p[3 * 64] = e.w21; p[4 * 64] = e.pm0;
     p[5 * 64] = e.pm1; p[6 * 64] = e.qm;  p[7 * 64] = e.sc0; p[8 * 64] = e.sc1; p[9 * 64] = e.qc;
 #endif
+#if VARIANT != 2
     seg = mg;
+#endif
   }
 }
 __global__ __launch_bounds__(256, 1) void k(double *out, unsigned long long *cyc, int reps) {
