@@ -28,6 +28,26 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
 #endif
   }
 }
+template <int l> __device__ __forceinline__ void down(double &dR0, double &dR1, double bL0, double bL1, int lane, const double *slots) {
+  constexpr int d = 1 << l;
+  double e0 = fetch_left<2 * d>(dR0, lane), e1 = fetch_left<2 * d>(dR1, lane);
+  if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
+  double m0 = 0, m1 = 0;
+#if VARIANT == 4
+  {
+#else
+  if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+#endif
+    Elim<double> e;
+    const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
+    const double *p = slots + slot;
+    e.w10 = p[0 * 64]; e.w11 = p[1 * 64]; e.w20 = p[2 * 64]; e.w21 = p[3 * 64]; e.pm0 = p[4 * 64];
+    e.pm1 = p[5 * 64]; e.qm = p[6 * 64];  e.sc0 = p[7 * 64]; e.sc1 = p[8 * 64]; e.qc = p[9 * 64];
+    back(e, e0, e1, dR0, dR1, m0, m1);
+  }
+  const double x0 = tree_from_above<d>(m0), x1 = tree_from_above<d>(m1);
+  if ((lane & (2 * d - 1)) == (d - 1)) { dR0 = x0; dR1 = x1; }
+}
 __global__ __launch_bounds__(256, 1) void k(double *out, unsigned long long *cyc, int reps) {
   __shared__ double tree[4][10][64];
   __shared__ double big[16000];            // keep one workgroup per CU like the real kernel
@@ -49,10 +69,24 @@ __global__ __launch_bounds__(256, 1) void k(double *out, unsigned long long *cyc
     up<3>(seg, lane, &tree[wave][0][0]); up<4>(seg, lane, &tree[wave][0][0]); up<5>(seg, lane, &tree[wave][0][0]);
     asm volatile("" : "+v"(seg.qc), "+v"(seg.qm), "+v"(seg.pc0), "+v"(seg.sm0));
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if VARIANT >= 3
+    double dR0 = seg.qc, dR1 = seg.qm;
+    const double *sl = &tree[wave][0][0];
+    asm volatile("" : "+v"(dR0), "+v"(dR1));
+    const unsigned long long t0b = __builtin_amdgcn_s_memtime();
+    down<5>(dR0, dR1, 0.1, 0.2, lane, sl); down<4>(dR0, dR1, 0.1, 0.2, lane, sl); down<3>(dR0, dR1, 0.1, 0.2, lane, sl);
+    down<2>(dR0, dR1, 0.1, 0.2, lane, sl); down<1>(dR0, dR1, 0.1, 0.2, lane, sl); down<0>(dR0, dR1, 0.1, 0.2, lane, sl);
+    asm volatile("" : "+v"(dR0), "+v"(dR1));
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    total += t1 - t0b;
+    acc += dR0 + dR1;
+#else
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
     total += t1 - t0;
     acc += seg.qc + seg.qm + seg.pc0 + seg.sm0;
+#endif
   }
   out[blockIdx.x * 256 + t] = acc + tree[wave][3][lane] + big[(t * 7) % 16000];
   if (lane == 0) cyc[blockIdx.x * 4 + wave] = total;
