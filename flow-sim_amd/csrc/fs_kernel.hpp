@@ -45,6 +45,9 @@
 #ifndef FS_PIN_SEG
 #define FS_PIN_SEG 1     // 1: keep each merge in its cell region (+3%), 2: additionally skewed by one cell (no further gain)
 #endif
+#ifndef FS_PHASE_FENCE
+#define FS_PHASE_FENCE 0
+#endif
 #ifndef FS_LDS_FIRST
 #define FS_LDS_FIRST 0
 #endif
@@ -605,6 +608,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       }
 
       FS_T(1);
+#if FS_PHASE_FENCE
+      __builtin_amdgcn_sched_barrier(0);   // phases are not interleaved: it only costs registers (measured around the down-sweep: +5 %)
+#endif
       // ================= 3. in-wave tree (up-sweep) =================
       constexpr bool L0R = TreeCfg<W>::kL0Regs;
       constexpr int TS = TreeCfg<W>::kSlots;
@@ -630,6 +636,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
       up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
       up_level(std::integral_constant<int, 4>{}); up_level(std::integral_constant<int, 5>{});
+#if FS_PHASE_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       nrm2 = wave_sum(nrm2);
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
@@ -685,35 +694,64 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
 
       FS_T(5);
       // ================= 6. separators down the tree, local back-substitution, update ============
-      R dR0 = bR0, dR1 = bR1;       // valid on lane 63; filled for every lane below
-      auto down_level = [&](auto lc) {
+      // Every lane carries the updates (aL, aR) at the two ends of the group of 2^(l+1) lanes it belongs
+      // to at the current level.  The group's elimination record is one LDS slot that all its lanes read
+      // (a broadcast read), each lane recovers the group's middle separator itself and keeps it as its
+      // new right end (lower half of the group) or left end (upper half): no cross-lane traffic and a
+      // dependent chain of four fp64 operations per level.
+      R aL0 = bL0, aL1 = bL1, aR0 = bR0, aR1 = bR1;
+      auto load_rec = [&](auto lc) {
         constexpr int l = decltype(lc)::value;
-        constexpr int d = 1 << l;
-        // left end of the merged pair: lane - 2d (a lane with all low bits set), or the wave's left boundary
-        // (row_shr inside a DPP row, row_bcast15/31 when lane - 2d sits in the row before: no LDS round trip)
-        R e0 = fetch_left<2 * d>(dR0, lane), e1 = fetch_left<2 * d>(dR1, lane);
-        if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
-        R m0 = R(0), m1 = R(0);
-        if ((lane & (2 * d - 1)) == (2 * d - 1)) {
-          Elim<R> e;
-          if (L0R && l == 0) {
-            e = e_l0;
-          } else {
-            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
-            const R *p = &sm.tree[wave][0][slot];
-            e.w10 = p[0 * TS]; e.w11 = p[1 * TS]; e.w20 = p[2 * TS]; e.w21 = p[3 * TS]; e.pm0 = p[4 * TS];
-            e.pm1 = p[5 * TS]; e.qm = p[6 * TS];  e.sc0 = p[7 * TS]; e.sc1 = p[8 * TS]; e.qc = p[9 * TS];
-          }
-          back(e, e0, e1, dR0, dR1, m0, m1);
+        Elim<R> e;
+        if (L0R && l == 0) {
+          // level-0 records live in the odd lanes' registers: both lanes of a pair take the odd lane's copy
+          auto pair = [](R v) { return dpp_mov<0xF5>(v); };     // quad_perm:[1,1,3,3]
+          e.w10 = pair(e_l0.w10); e.w11 = pair(e_l0.w11); e.w20 = pair(e_l0.w20); e.w21 = pair(e_l0.w21);
+          e.pm0 = pair(e_l0.pm0); e.pm1 = pair(e_l0.pm1); e.qm = pair(e_l0.qm);
+          e.sc0 = pair(e_l0.sc0); e.sc1 = pair(e_l0.sc1); e.qc = pair(e_l0.qc);
+        } else {
+          const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
+          const R *p = &sm.tree[wave][0][slot];
+          e.w10 = p[0 * TS]; e.w11 = p[1 * TS]; e.w20 = p[2 * TS]; e.w21 = p[3 * TS]; e.pm0 = p[4 * TS];
+          e.pm1 = p[5 * TS]; e.qm = p[6 * TS];  e.sc0 = p[7 * TS]; e.sc1 = p[8 * TS]; e.qc = p[9 * TS];
         }
-        const R x0 = tree_from_above<d>(m0), x1 = tree_from_above<d>(m1);
-        if ((lane & (2 * d - 1)) == (d - 1)) { dR0 = x0; dR1 = x1; }
+        return e;
       };
-      down_level(std::integral_constant<int, 5>{}); down_level(std::integral_constant<int, 4>{});
-      down_level(std::integral_constant<int, 3>{}); down_level(std::integral_constant<int, 2>{});
-      down_level(std::integral_constant<int, 1>{}); down_level(std::integral_constant<int, 0>{});
-      R dL0 = wave_shr1(dR0), dL1 = wave_shr1(dR1);
-      if (lane == 0) { dL0 = bL0; dL1 = bL1; }
+      auto down_level = [&](auto lc, const Elim<R> &e) {
+        constexpr int l = decltype(lc)::value;
+        R m0, m1;
+        back(e, aL0, aL1, aR0, aR1, m0, m1);
+        const bool upper = ((lane >> l) & 1) != 0;
+        aL0 = upper ? m0 : aL0; aL1 = upper ? m1 : aL1;
+        aR0 = upper ? aR0 : m0; aR1 = upper ? aR1 : m1;
+      };
+      {
+        // records are requested exactly one level ahead (the memory clobbers keep the compiler from
+        // requesting all six up front, which costs 120 registers and sends the kernel to scratch)
+        using I5 = std::integral_constant<int, 5>; using I4 = std::integral_constant<int, 4>;
+        using I3 = std::integral_constant<int, 3>; using I2 = std::integral_constant<int, 2>;
+        using I1 = std::integral_constant<int, 1>; using I0 = std::integral_constant<int, 0>;
+        __builtin_amdgcn_sched_barrier(0);
+        const Elim<R> r5 = load_rec(I5{}), r4 = load_rec(I4{});
+        asm volatile("" ::: "memory");
+        down_level(I5{}, r5);
+        const Elim<R> r3 = load_rec(I3{});
+        asm volatile("" ::: "memory");
+        down_level(I4{}, r4);
+        const Elim<R> r2 = load_rec(I2{});
+        asm volatile("" ::: "memory");
+        down_level(I3{}, r3);
+        const Elim<R> r1 = load_rec(I1{});
+        asm volatile("" ::: "memory");
+        down_level(I2{}, r2);
+        const Elim<R> r0 = load_rec(I0{});
+        asm volatile("" ::: "memory");
+        down_level(I1{}, r1);
+        down_level(I0{}, r0);
+        asm volatile("" : "+v"(aL0), "+v"(aL1), "+v"(aR0), "+v"(aR1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      const R dR0 = aR0, dR1 = aR1, dL0 = aL0, dL1 = aL1;
 
       // The update is kept pending in dh/dQ (they take the registers the elimination records free up):
       // the accepted iterate must still be intact for the level-constant pass below.
@@ -752,6 +790,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         }
       }
       FS_T(6);
+#if FS_PHASE_FENCE
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 
       // ================= 5. accepted iterate -> level k =================
       if (converged) {

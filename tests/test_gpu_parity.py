@@ -205,6 +205,26 @@ def test_full_width_reach_against_oracle():
         assert np.array_equal(its[:, i], out["iters"])
 
 
+def test_eight_wave_shape_on_a_full_width_reach(monkeypatch):
+    """M = 8, W = 8 (two waves per SIMD; level-0 tree records kept in registers and handed to the
+    pair lane by quad_perm in the down-sweep): not the default shape, selected here through the override."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle
+    from synth import rect_problem
+    monkeypatch.setenv("FS_KERNEL_SHAPE", "8,8")
+    probs = [rect_problem(4096, seed=s, n_steps=2) for s in (21, 22)]
+    with batch_from_problems(probs) as b:
+        b.step(2)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+        info = b.kernel_info()
+    assert (info["cells_per_thread"], info["waves_per_reach"]) == (8, 8)
+    for i, p in enumerate(probs):
+        out = c_oracle.run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL and rel_err(Q[:, i], out["flow"], 1.0) <= TOL
+        assert np.array_equal(its[:, i], out["iters"])
+
+
 def test_max_iter_and_status_reporting():
     """max_iter exhausted -> status 1 and the level is not advanced (preissmann.py:124-126)."""
     from fixture_batch import batch_from_problems
