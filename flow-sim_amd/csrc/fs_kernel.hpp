@@ -46,7 +46,7 @@
 #define FS_PIN_SEG 1     // 1: keep each merge in its cell region (+3%), 2: additionally skewed by one cell (no further gain)
 #endif
 #ifndef FS_PHASE_FENCE
-#define FS_PHASE_FENCE 0
+#define FS_PHASE_FENCE 8   // bit 3: pin the back-substituted updates and fence them off from the acceptance block (+0.9 %, 450 instead of 508 registers); bits 0-2 (other phase boundaries): no gain
 #endif
 #ifndef FS_LDS_FIRST
 #define FS_LDS_FIRST 0
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       }
 
       FS_T(1);
-#if FS_PHASE_FENCE
+#if FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);   // phases are not interleaved: it only costs registers (measured around the down-sweep: +5 %)
 #endif
       // ================= 3. in-wave tree (up-sweep) =================
@@ -636,7 +636,12 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
       up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
       up_level(std::integral_constant<int, 4>{}); up_level(std::integral_constant<int, 5>{});
-#if FS_PHASE_FENCE
+#if FS_PHASE_FENCE & 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#if FS_PHASE_FENCE & 4
+      asm volatile("" : "+v"(seg.pc0), "+v"(seg.pc1), "+v"(seg.sc0), "+v"(seg.sc1), "+v"(seg.qc));
+      asm volatile("" : "+v"(seg.pm0), "+v"(seg.pm1), "+v"(seg.sm0), "+v"(seg.sm1), "+v"(seg.qm));
       __builtin_amdgcn_sched_barrier(0);
 #endif
       nrm2 = wave_sum(nrm2);
@@ -684,6 +689,10 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         for (int w = 1; w < W; ++w)
           if (wave == w) { bL0 = bnd[w][0]; bL1 = bnd[w][1]; bR0 = bnd[w + 1][0]; bR1 = bnd[w + 1][1]; }
       }
+#if FS_PHASE_FENCE & 2
+      asm volatile("" : "+v"(bL0), "+v"(bL1), "+v"(bR0), "+v"(bR1), "+v"(tot));
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       FS_T(4);
       const R err = sqrt_(tot);                                        // utility.py:20-22
       if (sm.xflag[parity] != 0) status = sm.xflag[parity];
@@ -790,7 +799,11 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         }
       }
       FS_T(6);
-#if FS_PHASE_FENCE
+#if FS_PHASE_FENCE & 8
+#pragma unroll
+      for (int j = 1; j < M; ++j) asm volatile("" : "+v"(dh[j]), "+v"(dQ[j]));
+      __builtin_amdgcn_sched_barrier(0);
+#elif FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);
 #endif
 
