@@ -711,7 +711,7 @@ template <typename R> __device__ __forceinline__ R shfl_(R v, int l) { return __
 #define FS_DPP 1
 #endif
 #ifndef FS_DPP_TIED
-#define FS_DPP_TIED 1   // 1: dst tied to the source (copy + in-place DPP); 0: bound_ctrl, no copy - faster in isolation, slower inside the kernel
+#define FS_DPP_TIED 0   // 0: bound_ctrl moves without a tied destination (no register copy per move); 1: copy + in-place DPP
 #endif
 // lanes without a source read 0 (bound_ctrl): their value is unspecified for every caller below, and an
 // "old" operand that never shows through spares the register copy that keeps v alive next to its shifted copy

@@ -13,9 +13,18 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
   const Seg<double> left = seg_from_below<d>(seg);
   Seg<double> mg; Elim<double> e;
   merge(left, seg, mg, e);
-#if VARIANT == 2
+#if VARIANT == 2 || VARIANT == 6
   seg = mg;       // every lane: the lanes that do not survive this level are never read again
 #endif
+#if VARIANT == 6
+  {
+    const bool sv = (lane & (2 * d - 1)) == (2 * d - 1);
+    const int slot = sv ? (64 - (64 >> l)) + (lane >> (l + 1)) : 63;
+    double *p = slots + slot;
+    p[0 * 64] = e.w10; p[1 * 64] = e.w11; p[2 * 64] = e.w20; p[3 * 64] = e.w21; p[4 * 64] = e.pm0;
+    p[5 * 64] = e.pm1; p[6 * 64] = e.qm;  p[7 * 64] = e.sc0; p[8 * 64] = e.sc1; p[9 * 64] = e.qc;
+  }
+#else
   if ((lane & (2 * d - 1)) == (2 * d - 1)) {
 #if VARIANT != 1
     const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
@@ -27,6 +36,7 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
     seg = mg;
 #endif
   }
+#endif
 }
 template <int l> __device__ __forceinline__ void down(double &dR0, double &dR1, double bL0, double bL1, int lane, const double *slots) {
   constexpr int d = 1 << l;
