@@ -699,9 +699,6 @@ __device__ __forceinline__ void close_system(const Seg<R> &S, const BCRow<R> &U,
 // ---------------------------------------------------------------------------------------------
 // cross-lane plumbing (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------------
-template <typename R> __device__ __forceinline__ R shfl_up_(R v, int d) { return __shfl_up(v, d, 64); }
-template <typename R> __device__ __forceinline__ R shfl_dn_(R v, int d) { return __shfl_down(v, d, 64); }
-template <typename R> __device__ __forceinline__ R shfl_(R v, int l) { return __shfl(v, l, 64); }
 
 // Cross-lane moves without the LDS crossbar: DPP modifiers on v_mov_b32 (gfx9 family).
 //   row_shr:n / row_shl:n  move within a row of 16 lanes; row_bcast15 / row_bcast31 hand lane 15 of
@@ -735,47 +732,6 @@ template <int D, typename R> __device__ __forceinline__ R tree_from_below(R v) {
   return __shfl_up(v, D, 64);
 #endif
 }
-// gfx950 lane-permute swaps: second result of v_permlane16_swap / v_permlane32_swap with both operands = v,
-// i.e. rows 0/2 receive rows 1/3 (16) or the lower half receives the upper half (32)
-__device__ __forceinline__ int swap16_(int v) { return (int)__builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false)[1]; }
-__device__ __forceinline__ int swap32_(int v) { return (int)__builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false)[1]; }
-__device__ __forceinline__ double swap16_(double v) { return __hiloint2double(swap16_(__double2hiint(v)), swap16_(__double2loint(v))); }
-__device__ __forceinline__ double swap32_(double v) { return __hiloint2double(swap32_(__double2hiint(v)), swap32_(__double2loint(v))); }
-__device__ __forceinline__ float swap16_(float v) { return __int_as_float(swap16_(__float_as_int(v))); }
-__device__ __forceinline__ float swap32_(float v) { return __int_as_float(swap32_(__float_as_int(v))); }
-
-// value of lane + D for lanes with (lane & (2D-1)) == D-1 (others: unspecified)
-template <int D, typename R> __device__ __forceinline__ R tree_from_above(R v) {
-#if FS_DPP
-  if (D < 16) return dpp_mov<0x100 + (D < 16 ? D : 1)>(v);      // row_shl:D
-  if (D == 16) return swap16_(v);                                 // lanes 15, 47 <- lanes 31, 63
-  return swap32_(v);                                              // lane 31 <- lane 63
-#else
-  return __shfl_down(v, D, 64);
-#endif
-}
-// value of lane - D2 for lanes with (lane & (D2-1)) == D2-1 and lane >= D2 (others: unspecified)
-template <int D2, typename R> __device__ __forceinline__ R fetch_left(R v, int lane) {
-#if FS_DPP
-  if (D2 >= 64) return v;
-  if (D2 == 32) return dpp_mov<0x143>(v);                         // row_bcast31: lane 63 <- lane 31
-  const R up = dpp_mov<0x142>(v);                                 // row_bcast15: every row <- lane 15 of the row before
-  if (D2 == 16) return up;
-  const R in_row = dpp_mov<0x110 + (D2 < 16 ? D2 : 1)>(v);        // row_shr:D2
-  return (lane & 15) == D2 - 1 ? up : in_row;                     // the first candidate of a row reaches into the row before
-#else
-  return __shfl_up(v, D2, 64);
-#endif
-}
-// value of lane - 1 (lane 0: unspecified)
-template <typename R> __device__ __forceinline__ R wave_shr1(R v) {
-#if FS_DPP
-  return dpp_mov<0x138>(v);                                       // wave_shr:1
-#else
-  return __shfl_up(v, 1, 64);
-#endif
-}
-
 template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(const Seg<R> &s) {
   Seg<R> o;
   o.pc0 = tree_from_below<D>(s.pc0); o.pc1 = tree_from_below<D>(s.pc1); o.sc0 = tree_from_below<D>(s.sc0);

@@ -1,4 +1,5 @@
-// cycles of the in-wave up-sweep (6 levels) and down-sweep of fs_kernel.hpp in isolation, one wave per SIMD
+// cycles of the in-wave up-sweep (6 levels; VARIANT 0 as in the kernel's first version, 1 without record stores,
+// 2 every lane merges) and, VARIANT >= 3, of the broadcast down-sweep of fs_kernel.hpp, one wave per SIMD
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
@@ -38,26 +39,6 @@ template <int l> __device__ __forceinline__ void up(Seg<double> &seg, int lane, 
   }
 #endif
 }
-template <int l> __device__ __forceinline__ void down(double &dR0, double &dR1, double bL0, double bL1, int lane, const double *slots) {
-  constexpr int d = 1 << l;
-  double e0 = fetch_left<2 * d>(dR0, lane), e1 = fetch_left<2 * d>(dR1, lane);
-  if (lane < 2 * d) { e0 = bL0; e1 = bL1; }
-  double m0 = 0, m1 = 0;
-#if VARIANT == 4
-  {
-#else
-  if ((lane & (2 * d - 1)) == (2 * d - 1)) {
-#endif
-    Elim<double> e;
-    const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
-    const double *p = slots + slot;
-    e.w10 = p[0 * 64]; e.w11 = p[1 * 64]; e.w20 = p[2 * 64]; e.w21 = p[3 * 64]; e.pm0 = p[4 * 64];
-    e.pm1 = p[5 * 64]; e.qm = p[6 * 64];  e.sc0 = p[7 * 64]; e.sc1 = p[8 * 64]; e.qc = p[9 * 64];
-    back(e, e0, e1, dR0, dR1, m0, m1);
-  }
-  const double x0 = tree_from_above<d>(m0), x1 = tree_from_above<d>(m1);
-  if ((lane & (2 * d - 1)) == (d - 1)) { dR0 = x0; dR1 = x1; }
-}
 template <int l> __device__ __forceinline__ void down_b(double &aL0, double &aL1, double &aR0, double &aR1, int lane, const double *slots) {
   Elim<double> e;
   const int slot = (64 - (64 >> l)) + (lane >> (l + 1));
@@ -96,15 +77,10 @@ __global__ __launch_bounds__(256, 1) void k(double *out, unsigned long long *cyc
     const double *sl = &tree[wave][0][0];
     asm volatile("" : "+v"(dR0), "+v"(dR1));
     const unsigned long long t0b = __builtin_amdgcn_s_memtime();
-#if VARIANT == 5
     { double aL0 = 0.1, aL1 = 0.2, aR0 = dR0, aR1 = dR1;
       down_b<5>(aL0, aL1, aR0, aR1, lane, sl); down_b<4>(aL0, aL1, aR0, aR1, lane, sl); down_b<3>(aL0, aL1, aR0, aR1, lane, sl);
       down_b<2>(aL0, aL1, aR0, aR1, lane, sl); down_b<1>(aL0, aL1, aR0, aR1, lane, sl); down_b<0>(aL0, aL1, aR0, aR1, lane, sl);
       dR0 = aR0 + aL0; dR1 = aR1 + aL1; }
-#else
-    down<5>(dR0, dR1, 0.1, 0.2, lane, sl); down<4>(dR0, dR1, 0.1, 0.2, lane, sl); down<3>(dR0, dR1, 0.1, 0.2, lane, sl);
-    down<2>(dR0, dR1, 0.1, 0.2, lane, sl); down<1>(dR0, dR1, 0.1, 0.2, lane, sl); down<0>(dR0, dR1, 0.1, 0.2, lane, sl);
-#endif
     asm volatile("" : "+v"(dR0), "+v"(dR1));
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_sched_barrier(0);
