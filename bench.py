@@ -280,7 +280,7 @@ def main():
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
                          "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},
         }
-        if not args.no_cpu_baseline and args.workload == "c3":
+        if not args.no_cpu_baseline and args.workload == "c3" and world == 1:      # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
             out["cpu_baseline_c"] = cpu_baseline(N, dt, dx, theta, tol, compiled=True)
         print(json.dumps(out), flush=True)
