@@ -10,12 +10,14 @@
 //     to 4 constants per cell, kept in LDS, written once per level, read once per iteration;
 //   * the 2x2-block banded Jacobian is never materialised: each cell's 8 entries
 //     (preissmann.py:407-733) are folded straight into the lane's running segment
-//     (fs_device.hpp), the 64*W lane segments are reduced by a log-depth tree with wavefront
-//     shuffles (levels inside a wave) and LDS (across waves), the two boundary rows close the
-//     system, separators come back down the tree and each lane back-substitutes its chunk;
-//   * HBM is touched once per level per node: the accepted iterate is written as level k
-//     (preissmann.py:166-177; SURVEY F2: it is the pre-update iterate) and read back only by the
-//     next launch.  Boundary hydrographs and iteration counts go to small per-level tables.
+//     (fs_device.hpp); the 64*W lane segments are reduced by a log-depth tree - DPP moves inside a
+//     wave, one LDS mailbox and one barrier across waves - the two boundary rows close the system,
+//     the separators come back down (every lane tracks both ends of its group and reads the group's
+//     record from LDS: no cross-lane traffic) and each lane back-substitutes its chunk;
+//   * HBM is read once per launch and written at its last level (every level only into an optional
+//     history): the accepted iterate of level k (preissmann.py:166-177; SURVEY F2: the pre-update
+//     iterate) seeds the level constants of k+1 straight from registers.  Boundary hydrographs and
+//     iteration counts go to small per-level tables.
 //
 // Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
 // RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
