@@ -511,8 +511,9 @@ __device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, i
     } break;
     case FS_BC_RATING_POWER: {
       const R x = p(3) + h + p(2);
-      r.res = Q - p(0) * pow_(x, p(1));
-      r.dh = R(0) - p(0) * p(1) * pow_(x, p(1) - R(1));
+      const R q = p(0) * pow_(x, p(1));                                 // rating_curve.py:59
+      r.res = Q - q;
+      r.dh = R(0) - p(1) * q / x;                                       // a b x^(b-1) (:143) from the one pow()
       r.dq = R(1);
     } break;
     case FS_BC_RATING_POLY: {

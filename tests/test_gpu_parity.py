@@ -205,6 +205,53 @@ def test_full_width_reach_against_oracle():
         assert np.array_equal(its[:, i], out["iters"])
 
 
+def test_api_misuse_is_reported_not_computed():
+    """Argument checks of the C ABI: the messages of the reference where it has them
+    (boundary.py:33, :83-87), otherwise a plain description; nothing runs with a half-configured batch."""
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+    import ctypes as C
+    E = A.FlowsimError
+    for bad in ((0, 30, 5), (1, 1, 5), (1, 30, 1), (1, 5000, 5)):
+        with pytest.raises(E, match="n_reaches >= 1|no kernel instantiation"):
+            PreissmannBatch(*bad)
+    with PreissmannBatch(2, 40, 6) as b:
+        lib = b._lib
+        with pytest.raises(E, match="must be set first"):
+            b.step(1)
+        with pytest.raises(E, match="dt, dx, tolerance > 0"):
+            b.set_scheme(0.6, -1.0, 100.0, 1e-6, 10)
+        b.set_scheme(0.6, 600.0, 250.0, 1e-6, 50)
+        with pytest.raises(E, match="width and Manning n must be positive"):
+            b.set_geometry_uniform([100.0, -1.0], [0.03, 0.03], [1.0, 1.0], [0.0, 0.0])
+        with pytest.raises(E, match="another section_mode"):
+            b.set_geometry_table({k: np.zeros(40) for k in A.GEO_ROWS})
+        b.set_geometry_uniform([100.0, 120.0], [0.03, 0.03], [1.0, 1.0], [0.0, 0.0])
+        assert lib.fs_batch_set_bc(b._h, 2, A.BC_FIXED_DEPTH, None, 0, 0, None) != 0        # bad side
+        assert b"side" in lib.fs_last_error()
+        assert lib.fs_batch_set_bc(b._h, A.UPSTREAM, 99, None, 0, 0, None) != 0
+        assert lib.fs_last_error() == b"Invalid boundary condition."
+        assert lib.fs_batch_set_bc(b._h, A.UPSTREAM, A.BC_FLOW_HYDROGRAPH, None, 0, 0, None) != 0   # no hydrograph
+        assert lib.fs_last_error() == b"Insufficient arguments for boundary condition."
+        p = (C.c_double * 5)(1.0e5, 1.0, 0.0, 50.0, 0.0)
+        assert lib.fs_batch_set_bc(b._h, A.UPSTREAM, A.BC_STORAGE, p, 5, 0, None) != 0             # storage upstream
+        assert b"downstream only" in lib.fs_last_error()
+        b.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, np.full(6, 200.0)))
+        b.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_FIXED_DEPTH, dict(initial_depth=2.0)))
+        b.set_state_uniform([2.0, 2.0], [200.0, 200.0])
+        with pytest.raises(E, match="n_steps must be >= 1"):
+            b.step(0)
+        with pytest.raises(E, match="past max_levels"):
+            b.step(6)
+        b.step(5)
+        assert b.level == 5 and np.all(b.status() == 0)
+        with pytest.raises(E, match="past max_levels"):
+            b.step(1)
+    with PreissmannBatch(1, 40, 6) as nb:
+        with pytest.raises(E):
+            nb.history_arrays()                    # no FS_FLAG_HISTORY on this batch
+
+
 def test_eight_wave_shape_on_a_full_width_reach(monkeypatch):
     """M = 8, W = 8 (two waves per SIMD; level-0 tree records kept in registers and handed to the
     pair lane by quad_perm in the down-sweep): not the default shape, selected here through the override."""
