@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flow-sim_amd"))
 sys.path.insert(0, ROOT)
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6    # vector fp64: 256 CUs x 4 SIMDs x 16 lanes x 2 flop (FMA) x 2.4 GHz
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, the unit this kernel actually runs on
 
@@ -285,6 +286,15 @@ def main():
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
                          "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},
         }
+        fj = os.path.join(ROOT, "profiles", "round1", "fp64_flops.json")
+        if os.path.exists(fj) and N == 4096 and args.dtype == "f64" and args.workload == "c3":
+            # informational second roofline: the kernel is bound by fp64 vector issue, not by HBM
+            fpi = json.load(open(fj))["fp64_flops_per_reach_iteration"]
+            tf = fpi * float(it_t[0].item()) / world / (kern_ms * 1e-3) / 1e12
+            out["roofline_compute"] = {"bound": "valu_f64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                                       "source": "profiles/round1/fp64_flops.json (rocprofv3 SQ_INSTS_VALU_*_F64 per Newton iteration "
+                                                 "x the iterations of this launch)"}
         if not args.no_cpu_baseline and args.workload == "c3" and world == 1:      # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
             out["cpu_baseline_c"] = cpu_baseline(N, dt, dx, theta, tol, compiled=True)

@@ -7,7 +7,7 @@ q = lambda r: ','.join('"%s"' % c for c in r)
 rows = list(csv.reader(open(newest(f'{P}/trace/runc/*_kernel_trace.csv'))))
 open(f'{D}/kernel_trace_preissmann.csv', 'w').write('\n'.join(q(r) for r in rows if r and (r[0] == 'Kind' or 'preissmann' in ','.join(r))) + '\n')
 vals = {}
-for name in ('pmc_fetch', 'pmc_write', 'pmc_sq'):
+for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_flops'):
     rows = list(csv.reader(open(newest(f'{P}/{name}/runc/*_counter_collection.csv'))))
     keep = [r for r in rows if r and (r[0] == 'Correlation_Id' or 'preissmann' in ','.join(r))]
     open(f'{D}/{name}_preissmann.csv', 'w').write('\n'.join(q(r) for r in keep) + '\n')
@@ -25,3 +25,14 @@ print(open(f'{D}/kernel_stats.csv').read().split('\n')[1][:200])
 print('fetch GB', fetch / 1e9, 'write GB', write / 1e9, 'per reach-timestep', (fetch + write) / (B * K))
 w = vals['SQ_WAVES']
 print({k: f'{v / w:.4g}' for k, v in vals.items() if k.startswith('SQ_INSTS')}, 'valu active', vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_WAVE_CYCLES'])
+
+# fp64 work per Newton iteration of one reach (wave-instruction counts x 64 lanes; an FMA is two flops)
+bj = json.loads(open(f'{P}/bench_flops.json').read().strip().split('\n')[-1])
+its = bj['config']['mean_newton_iterations_per_step']
+flops = 64 * (2 * vals['SQ_INSTS_VALU_FMA_F64'] + vals['SQ_INSTS_VALU_MUL_F64'] + vals['SQ_INSTS_VALU_ADD_F64'] + vals['SQ_INSTS_VALU_TRANS_F64'])
+json.dump({"source": "rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (tools/profile.sh), last launch of the run",
+           "workload": "65536 reaches x 4096 nodes, 8 steps in one launch", "mean_newton_iterations_per_step": its,
+           "fp64_flops_per_launch": flops, "fp64_flops_per_reach_iteration": flops / (B * K * its),
+           "valu_instructions_per_wave_iteration": vals['SQ_INSTS_VALU'] / vals['SQ_WAVES'] / (K * its)},
+          open(f'{D}/fp64_flops.json', 'w'), indent=1)
+print('fp64 flops per reach-iteration', flops / (B * K * its))
