@@ -29,9 +29,6 @@
 #include "fs_poly.hpp"
 
 // build-time experiment switches (defaults = the configuration that measured fastest)
-#ifndef FS_SKEW
-#define FS_SKEW 0
-#endif
 #ifndef FS_CELL_FENCE
 #define FS_CELL_FENCE 1
 #endif
@@ -45,7 +42,7 @@
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
 #ifndef FS_PIN_SEG
-#define FS_PIN_SEG 1     // 1: keep each merge in its cell region (+3%), 2: additionally skewed by one cell (no further gain)
+#define FS_PIN_SEG 1     // keep each merge in its cell's scheduling region (+3 % at M >= 8)
 #endif
 #ifndef FS_PHASE_FENCE
 #define FS_PHASE_FENCE 8   // bit 3: pin the back-substituted updates and fence them off from the acceptance block (+0.9 %, 450 instead of 508 registers); bits 0-2 (other phase boundaries): no gain
@@ -270,7 +267,7 @@ template <typename R, int M, int W> struct Smem {
 // continuity row of cell j that completes the block (T_j/(2dt), -+theta/dx and its residual) is
 // recomputed from the still un-updated state when the top width is constant (kConstT), else its
 // residual is kept in qc.
-template <typename R> struct LocalElim { Parked<R> rs0, rs1, rp0, rp1, rq, qc; };   // lives in AGPRs
+template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
 template <typename R, int SEC, int M, int W, bool RAGGED = true, bool BCFAST = false>
 __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
@@ -400,103 +397,16 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       asm volatile("" : "+v"(ln));
       const R *kcb = &sm.kc[0][0][0] + kco;
 
-#if FS_SKEW
-      // ================= 1. local assembly + fold (registers only) =================
-      // Software-pipelined by one cell: block c assembles cell c (independent work: two reciprocals,
-      // an x^(-1/3), ~45 flops) next to the merge of cell c-1 into the running segment (the serial
-      // chain).  Each cell sits in its own basic block behind an always-true uniform branch the
-      // compiler cannot fold: instruction selection works per block, so the M cells keep their
-      // order instead of being re-sorted into "all coefficients first, merge chain last" with 10*M
-      // values parked in between.
-      LocalElim<R> el[M > 1 ? M - 1 : 1];
-      R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
-      Seg<R> seg, pend;
-      R nrm2 = R(0);
-      {
-        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
-        if (!Geo::kConstT) Tn[0] = L.T;
-#pragma unroll
-        for (int c = 0; c <= M; ++c) {
-          if (a.level0 > c - 65536) {            // opaque, uniform, always true
-            if (c >= 2) {
-              // merge(seg, pend): pend is cell c-1, the shared node is local node c-1
-              const R det = seg.sm0 * pend.pc1 - seg.sm1 * pend.pc0;
-              const R r = frcp(det);
-              LocalElim<R> &e = el[c - 2];
-              e.rs0.put(r * seg.sm0); e.rs1.put(r * seg.sm1); e.rp0.put(r * seg.pm0); e.rp1.put(r * seg.pm1);
-              e.rq.put(r * seg.qm);
-              if (!Geo::kConstT) e.qc.put(pend.qc);
-              const R w10 = pend.pc1 * r, w11 = -pend.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
-              const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
-              const R ga = pend.pm0 * w10 + pend.pm1 * w11, ep = pend.pm0 * w20 + pend.pm1 * w21;
-              Seg<R> o;
-              o.pc0 = seg.pc0 - al * seg.pm0; o.pc1 = seg.pc1 - al * seg.pm1;
-              o.sc0 = -be * pend.sc0;         o.sc1 = -be * pend.sc1;
-              o.qc = seg.qc - al * seg.qm - be * pend.qc;
-              o.pm0 = -ga * seg.pm0;          o.pm1 = -ga * seg.pm1;
-              o.sm0 = pend.sm0 - ep * pend.sc0; o.sm1 = pend.sm1 - ep * pend.sc1;
-              o.qm = pend.qm - ga * seg.qm - ep * pend.qc;
-              seg = o;
-            } else if (c == 1) {
-              seg = pend;
-            }
-            if (c < M) {
-              const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
-              if (!Geo::kConstT) Tn[c + 1] = Rn.T;
-              // identity padding d_{i+1} = d_i beyond the last cell
-              const bool real = (RAGGED || c == M - 1) ? (s0 + c < NC) : true;
-              const R sumA = L.A + Rn.A;
-              const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + kcb[(0 * M + c) * T];          // :220-249
-              const R avgA = hth * sumA + kcb[(2 * M + c) * T];
-              const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + kcb[(3 * M + c) * T];
-              const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + kcb[(1 * M + c) * T] +
-                             g * avgA * S;                                                     // :251-301
-              nrm2 += real ? Cres * Cres + Mres * Mres : R(0);
-              const R gA = g * avgA, gS = g * hth * S;
-              pend.pc0 = real ? L.T * r2dt : R(1);   pend.pc1 = real ? -cq : R(0);             // :431-447, :476-491
-              pend.sc0 = real ? Rn.T * r2dt : R(-1); pend.sc1 = real ? cq : R(0);              // :407-422, :456-471
-              pend.qc = real ? -Cres : R(0);
-              pend.pm0 = real ? cq * L.v * L.v * L.T + gA * (hth * L.eA - cq) + gS * L.T : R(0);        // :558-612
-              pend.pm1 = real ? r2dt - cq * R(2) * L.v + gA * hth * L.eQ : R(1);                         // :677-733
-              pend.sm0 = real ? -cq * Rn.v * Rn.v * Rn.T + gA * (hth * Rn.eA + cq) + gS * Rn.T : R(0);  // :496-550
-              pend.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
-              pend.qm = real ? -Mres : R(0);
-              L = Rn;
-            }
-          }
-        }
-        if (M == 1) seg = pend;
-      }
-
-#else
       // ================= 1. local assembly + fold (registers only) =================
       LocalElim<R> el[M > 1 ? M - 1 : 1];
       R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
       Seg<R> seg;
+      R pf0 = R(0), pf1 = R(0);                // M-like row of the lane's first cell (left part)
       R nrm2 = R(0);
-      // merge(sg, cell) keeping only what the local back-substitution reads
-      auto fold_merge = [&](Seg<R> &sg, const Seg<R> &cell, LocalElim<R> &e) {
-        const R det = sg.sm0 * cell.pc1 - sg.sm1 * cell.pc0;
-        const R r = frcp(det);
-        e.rs0.put(r * sg.sm0); e.rs1.put(r * sg.sm1); e.rp0.put(r * sg.pm0); e.rp1.put(r * sg.pm1);
-        e.rq.put(r * sg.qm);
-        if (!Geo::kConstT) e.qc.put(cell.qc);
-        const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -sg.sm1 * r, w21 = sg.sm0 * r;
-        const R al = sg.sc0 * w10 + sg.sc1 * w11, be = sg.sc0 * w20 + sg.sc1 * w21;
-        const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
-        Seg<R> o;
-        o.pc0 = sg.pc0 - al * sg.pm0; o.pc1 = sg.pc1 - al * sg.pm1;
-        o.sc0 = -be * cell.sc0;         o.sc1 = -be * cell.sc1;
-        o.qc = sg.qc - al * sg.qm - be * cell.qc;
-        o.pm0 = -ga * sg.pm0;          o.pm1 = -ga * sg.pm1;
-        o.sm0 = cell.sm0 - ep * cell.sc0; o.sm1 = cell.sm1 - ep * cell.sc1;
-        o.qm = cell.qm - ga * sg.qm - ep * cell.qc;
-        sg = o;
-      };
       {
         NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
         if (!Geo::kConstT) Tn[0] = L.T;
-        Seg<R> prev;
+        R kap = R(1);                      // the M-like row keeps the direction of cell 0's: pm = kap * (pf0, pf1)
 #if FS_LDS_FIRST
         R kn0 = kcb[(0 * M) * T], kn1 = kcb[(1 * M) * T], kn2 = kcb[(2 * M) * T], kn3 = kcb[(3 * M) * T];
 #endif
@@ -535,61 +445,49 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
             cell.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
             cell.qm = real ? -Mres : R(0);
           }
-#if FS_PIN_SEG == 2
-          // software pipeline by one cell: this region merges cell c-1 (a serial chain) next to the
-          // independent assembly of cell c
-          if (c == 1) {
-            seg = prev;
-          } else if (c >= 2) {
-            fold_merge(seg, prev, el[c - 2]);
-          }
-          prev = cell;
-          asm volatile("" :: "v"(prev.pc0), "v"(prev.sc0), "v"(prev.qc), "v"(prev.pm0), "v"(prev.pm1), "v"(prev.sm0),
-                             "v"(prev.sm1), "v"(prev.qm));
-#else
           if (c == 0) {
             seg = cell;
+            pf0 = cell.pm0; pf1 = cell.pm1;
           } else {
-            // merge(seg, cell) keeping only what the local back-substitution reads
+            // merge(seg, cell) keeping only what the local back-substitution reads.  The merged M-like row's
+            // left part is always a multiple of cell 0's (o.pm = -ga * seg.pm): only the factor kap is carried
+            // and recorded, which is one value per node less to park and one multiplication less per merge.
             const R det = seg.sm0 * cell.pc1 - seg.sm1 * cell.pc0;
             const R r = frcp(det);
             LocalElim<R> &e = el[c - 1];
-            e.rs0.put(r * seg.sm0); e.rs1.put(r * seg.sm1); e.rp0.put(r * seg.pm0); e.rp1.put(r * seg.pm1);
-            e.rq.put(r * seg.qm);
+            const R w21 = r * seg.sm0, rs1 = r * seg.sm1;
+            e.rs0.put(w21); e.rs1.put(rs1); e.rk.put(r * kap); e.rq.put(r * seg.qm);
             if (!Geo::kConstT) e.qc.put(cell.qc);
-            const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -seg.sm1 * r, w21 = seg.sm0 * r;
+            const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -rs1;
             const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
             const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
+            const R ak = al * kap;
             Seg<R> o;
-            o.pc0 = seg.pc0 - al * seg.pm0; o.pc1 = seg.pc1 - al * seg.pm1;
+            o.pc0 = seg.pc0 - ak * pf0;     o.pc1 = seg.pc1 - ak * pf1;
             o.sc0 = -be * cell.sc0;         o.sc1 = -be * cell.sc1;
             o.qc = seg.qc - al * seg.qm - be * cell.qc;
-            o.pm0 = -ga * seg.pm0;          o.pm1 = -ga * seg.pm1;
+            kap = -ga * kap;
+            o.pm0 = R(0);                   o.pm1 = R(0);          // materialised after the last cell
             o.sm0 = cell.sm0 - ep * cell.sc0; o.sm1 = cell.sm1 - ep * cell.sc1;
             o.qm = cell.qm - ga * seg.qm - ep * cell.qc;
             seg = o;
           }
-#endif
 #if FS_PIN_SEG
           // the running segment must exist here: keeps cell c's merge inside cell c's scheduling region
           // (otherwise the 15 merges sink below the last fence and every cell's coefficients are parked)
           // (long chunks only: with M <= 4 the cells' node terms interleave profitably, measured on C4)
-          if (M >= 8 && (FS_PIN_SEG == 1 || c >= 1))
+          if (M >= 8)
             asm volatile("" :: "v"(seg.pc0), "v"(seg.pc1), "v"(seg.sc0), "v"(seg.sc1), "v"(seg.qc),
-                               "v"(seg.pm0), "v"(seg.pm1), "v"(seg.sm0), "v"(seg.sm1), "v"(seg.qm));
+                               "v"(kap), "v"(seg.sm0), "v"(seg.sm1), "v"(seg.qm));
 #endif
           L = Rn;
 #if FS_CELL_FENCE
           if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
 #endif
         }
-#if FS_PIN_SEG == 2
-        if (M == 1) seg = prev;
-        else fold_merge(seg, prev, el[M - 2]);
-#endif
+        seg.pm0 = kap * pf0; seg.pm1 = kap * pf1;
       }
 
-#endif
       FS_T(0);
       // ================= 2. boundary rows =================
       if (t == 0) {
@@ -779,6 +677,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
       }
       {
         R n0 = dR0, n1 = dR1;
+        const R pfL = pf0 * dL0 + pf1 * dL1;          // (first cell's M-like row) . (update at the lane's first node)
 #pragma unroll
         for (int j = M - 1; j >= 1; --j) {
           const LocalElim<R> &e = el[j - 1];
@@ -793,7 +692,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
           }
           const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
           if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
-          const R rsig = e.rq.get() - (e.rp0.get() * dL0 + e.rp1.get() * dL1);
+          const R rsig = e.rq.get() - e.rk.get() * pfL;
           const R tau = qc - (b0 * n0 + b1 * n1);
           n0 = c1 * rsig - e.rs1.get() * tau;
           n1 = e.rs0.get() * tau - c0 * rsig;
