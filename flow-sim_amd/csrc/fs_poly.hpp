@@ -34,30 +34,31 @@ template <typename R> struct PolyView { int lo, hi; bool vl, vr; R xl, xr, zc; }
 
 template <typename R> struct PolyEval { R A, P, Rh, T, neq, K, dRdA, dKdA, dAdh, y13; };
 
-// contribution of the edge (x0,z0)-(x1,z1) below stage hw; cross_section.py:286-322 edge by edge
+// contribution of the edge (x0,z0)-(x1,z1) below stage hw; cross_section.py:286-322 edge by edge.
+// dx, dz, len: the edge's extents and full length (an edge that is wet at both ends contributes its
+// whole length whatever the stage, so the square root is shared by the three stages of poly_eval).
 template <typename R>
-__device__ __forceinline__ void poly_edge(R x0, R z0, R x1, R z1, R hw, R &A, R &P, R &T) {
+__device__ __forceinline__ void poly_edge(R x0, R z0, R x1, R z1, R dx, R dz, R len, R hw, R &A, R &P, R &T) {
   const R d0 = hw - z0, d1 = hw - z1;
   const bool w0 = d0 > R(0), w1 = d1 > R(0);
   if (w0 && w1) {
-    const R dx = x1 - x0, dz = z1 - z0;
     A += R(0.5) * (d0 + d1) * dx;
-    P += sqrt_(dx * dx + dz * dz);
+    P += len;
     T += dx;
   } else if (w1 && z0 > hw) {                 // left water's edge, :289-296
-    const R t = (hw - z0) / (z1 - z0);
-    const R xl = x0 + t * (x1 - x0);
-    const R dx = x1 - xl, dz = z1 - hw;
-    A += R(0.5) * d1 * dx;
-    P += sqrt_(dx * dx + dz * dz);
-    T += dx;
+    const R t = (hw - z0) / dz;
+    const R xl = x0 + t * dx;
+    const R cx = x1 - xl, cz = z1 - hw;
+    A += R(0.5) * d1 * cx;
+    P += sqrt_(cx * cx + cz * cz);
+    T += cx;
   } else if (w0 && z1 > hw) {                 // right water's edge, :298-305
-    const R t = (hw - z0) / (z1 - z0);
-    const R xr = x0 + t * (x1 - x0);
-    const R dx = xr - x0, dz = hw - z0;
-    A += R(0.5) * d0 * dx;
-    P += sqrt_(dx * dx + dz * dz);
-    T += dx;
+    const R t = (hw - z0) / dz;
+    const R xr = x0 + t * dx;
+    const R cx = xr - x0, cz = hw - z0;
+    A += R(0.5) * d0 * cx;
+    P += sqrt_(cx * cx + cz * cz);
+    T += cx;
   }
 }
 
@@ -78,11 +79,14 @@ __device__ __noinline__ PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
   R x0 = xa, z0 = Z(j0);
   for (int j = j0; j < j1; ++j) {
     const R x1 = X(j + 1), z1 = Z(j + 1);
+    const R dx = x1 - x0, dz = z1 - z0;
+    // full length: needed as soon as both ends are wet at the highest of the three stages
+    const R len = (hw + dh > z0 && hw + dh > z1) ? sqrt_(dx * dx + dz * dz) : R(0);
     R eA = 0, eP = 0, eT = 0;
-    poly_edge(x0, z0, x1, z1, hw, eA, eP, eT);
+    poly_edge(x0, z0, x1, z1, dx, dz, len, hw, eA, eP, eT);
     A0 += eA; P0 += eP; T0 += eT;
-    poly_edge(x0, z0, x1, z1, hw - dh, A1, P1, Td);
-    poly_edge(x0, z0, x1, z1, hw + dh, A2, P2, Td);
+    poly_edge(x0, z0, x1, z1, dx, dz, len, hw - dh, A1, P1, Td);
+    poly_edge(x0, z0, x1, z1, dx, dz, len, hw + dh, A2, P2, Td);
     // roughness strips: an edge belongs to a strip when both of its stations pass the strip's mask (:459)
     if (x0 >= xa && x1 <= nd.liml) { Al += eA; Pl += eP; }
     if (x0 >= nd.liml && x1 <= nd.limr) { Am += eA; Pm += eP; }
@@ -196,7 +200,8 @@ __device__ __forceinline__ void poly_area_top(const PolyNode<R> &nd, R hw, R &A,
   R x0 = nd.x[0], z0 = nd.z[0];
   for (int j = 1; j < nd.n; ++j) {
     const R x1 = nd.x[(size_t)j * nd.stride], z1 = nd.z[(size_t)j * nd.stride];
-    poly_edge(x0, z0, x1, z1, hw, A, P, T);
+    const R dx = x1 - x0, dz = z1 - z0;
+    poly_edge(x0, z0, x1, z1, dx, dz, R(0), hw, A, P, T);        // the perimeter is not used here
     x0 = x1; z0 = z1;
   }
 }
