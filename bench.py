@@ -78,6 +78,52 @@ def cpu_baseline(N, dt, dx, theta, tol, budget_s=9.0, compiled=False):
                       + ("C oracle (gcc -O2, banded LU)" if compiled else "numpy+scipy.spsolve oracle") + f", {el:.1f} s"}
 
 
+def cpu_baseline_all_cores(N, dt, dx, theta, tol, cores, budget_s=6.0):
+    """The compiled C restatement over all host cores the process may use (threads over reaches; the
+    ctypes call releases the GIL).  Same workload definition, bounded sample."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import preissmann_oracle as O
+    from oracle import c_oracle as CO
+    try:
+        import psutil
+        psutil.Process().cpu_affinity(sorted(cores))          # undo the single-core pin of the legs above
+    except Exception:
+        pass
+    nthreads = min(len(cores), 64)      # bounded: the sample is set up in Python before the clock starts
+    per_thread, steps = 48, 4
+    R = nthreads * per_thread
+    b, n, S0, Qb = c3_reach_parameters(0, R)
+    hn = normal_depth_rect(b, n, S0, Qb)
+    tgt = inflow_table(Qb, steps + 1, dt)
+    L = (N - 1) * dx
+    ramp = 1 - np.arange(N) / (N - 1)
+    CO.lib()
+    problems = []                      # set up outside the timed region (numpy allocations hold the GIL)
+    for r in range(R):
+        geo = {k: np.zeros(N) for k in O.GEO_KEYS}
+        geo["b_main"][:] = b[r]; geo["n_main"][:] = n[r]; geo["n_left"][:] = n[r]; geo["n_right"][:] = n[r]
+        geo["z_bed"] = S0[r] * L * ramp
+        problems.append(O.Problem(geo=geo, h0=np.full(N, hn[r]), Q0=np.full(N, Qb[r]),
+                                  us=O.BC("flow_hydrograph", bed_level=S0[r] * L, target=tgt[:, r].copy()),
+                                  ds=O.BC("normal_depth", bed_level=0.0, bed_slope=float(S0[r])),
+                                  theta=theta, dt=dt, dx=dx, nt=steps + 1, tol=tol))
+    t0 = time.perf_counter()
+
+    def work(tid):
+        done = 0
+        for r in range(tid, R, nthreads):
+            CO.run(problems[r])
+            done += steps
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return done
+    with ThreadPoolExecutor(max_workers=nthreads) as ex:
+        done = sum(ex.map(work, range(nthreads)))
+    el = time.perf_counter() - t0
+    return {"value": done / el, "unit": "reach-timesteps/s", "cores": nthreads, "kind": "port",
+            "sample": f"{done // steps} reaches x {N} nodes x {steps} steps, C oracle on {nthreads} threads, {el:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -296,8 +342,10 @@ def main():
                                        "source": "profiles/round1/fp64_flops.json (rocprofv3 SQ_INSTS_VALU_*_F64 per Newton iteration "
                                                  "x the iterations of this launch)"}
         if not args.no_cpu_baseline and args.workload == "c3" and world == 1:      # reported at N=1 only
+            host_cores = set(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)
             out["cpu_baseline_c"] = cpu_baseline(N, dt, dx, theta, tol, compiled=True)
+            out["cpu_baseline_c_all_cores"] = cpu_baseline_all_cores(N, dt, dx, theta, tol, host_cores)
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:
