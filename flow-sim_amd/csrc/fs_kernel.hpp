@@ -35,9 +35,6 @@
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
 #endif
-#ifndef FS_CONST_VGPR
-#define FS_CONST_VGPR 0     // pin hot uniform constants in VGPRs (measured: no gain)
-#endif
 #ifndef FS_LEVEL_FENCE
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
@@ -46,9 +43,6 @@
 #endif
 #ifndef FS_PHASE_FENCE
 #define FS_PHASE_FENCE 8   // bit 3: pin the back-substituted updates and fence them off from the acceptance block (+0.9 %, 450 instead of 508 registers); bits 0-2 (other phase boundaries): no gain
-#endif
-#ifndef FS_LDS_FIRST
-#define FS_LDS_FIRST 0
 #endif
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
@@ -294,11 +288,6 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
   R hth = R(0.5) * th;
   const R hthk = R(0.5) * (R(1) - th);
   R g = R(kG);
-#if FS_CONST_VGPR
-  // The hot uniform constants are pinned in VGPRs: as SGPRs they are spilled to VGPR lanes under the
-  // scalar-register pressure of this kernel and re-read with two v_readlane per use (~240 per iteration).
-  asm volatile("" : "+v"(r2dt), "+v"(cq), "+v"(hth), "+v"(g));
-#endif
 
   // ---- unknowns of this lane: nodes s0 .. s0+M (clamped copies beyond the last node) ----
   R h[M + 1], Q[M + 1];
@@ -407,21 +396,9 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? FS_WPE_W1 : 1)) void preissmann_s
         NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
         if (!Geo::kConstT) Tn[0] = L.T;
         R kap = R(1);                      // the M-like row keeps the direction of cell 0's: pm = kap * (pf0, pf1)
-#if FS_LDS_FIRST
-        R kn0 = kcb[(0 * M) * T], kn1 = kcb[(1 * M) * T], kn2 = kcb[(2 * M) * T], kn3 = kcb[(3 * M) * T];
-#endif
 #pragma unroll
         for (int c = 0; c < M; ++c) {
-#if FS_LDS_FIRST
-          // level constants one cell ahead: requested in this scheduling region, consumed in the next
-          const R k0 = kn0, k1 = kn1, k2 = kn2, k3 = kn3;
-          if (c + 1 < M) {
-            kn0 = kcb[(0 * M + c + 1) * T]; kn1 = kcb[(1 * M + c + 1) * T];
-            kn2 = kcb[(2 * M + c + 1) * T]; kn3 = kcb[(3 * M + c + 1) * T];
-          }
-#else
           const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
-#endif
           const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
           if (!Geo::kConstT) Tn[c + 1] = Rn.T;
           Seg<R> cell;
