@@ -56,6 +56,8 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),   \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 1, true), \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, true), \
   FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1),          \
   FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1),          \
   FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 16, 4),  \
