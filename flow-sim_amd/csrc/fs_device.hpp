@@ -196,6 +196,15 @@ template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA, y
 // General trapezoid family (rectangle / simple / compound), straight from the reference including
 // the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
 // pow()-heavy and only the boundary rows and the TABLE geometry mode use it.
+// general boundary rows (bc_eval) in line or out of line
+#ifndef FS_BC_INLINE
+#define FS_BC_INLINE 1   // measured on the one-wave-per-reach kernels: C4 +8 %, C5 +4 % (fp64) / +15 % (fp32); a call inside the Newton loop spills the caller around it
+#endif
+#if FS_BC_INLINE
+#define FS_BC_ATTR __forceinline__
+#else
+#define FS_BC_ATTR __noinline__
+#endif
 #ifndef FS_GENERAL_INLINE
 #define FS_GENERAL_INLINE 1   // inline the general section evaluation into the fold (measured on C4: 4.5e6 -> 7.1e6)
 #endif
@@ -252,7 +261,7 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
 
 // out-of-line copy for the boundary rows (executed by two lanes per reach: keep it out of the hot code)
 template <typename R>
-__device__ __noinline__ GeneralProps<R> general_props_call(const SecParams<R> s, R h) { return general_props(s, h); }
+__device__ FS_BC_ATTR GeneralProps<R> general_props_call(const SecParams<R> s, R h) { return general_props(s, h); }
 
 // Curvature slope Sc and its derivatives (cross_section.py:145-175 over hydraulics.py:94-153) added to
 // (Se, dSe/dA, dSe/dQ).  T = geometric top width, dAdh = what the section reports as dA/dh (the same
@@ -488,7 +497,7 @@ __host__ __device__ inline bool bc_is_storage(int kind) { return kind == FS_BC_S
 // sec: section of the boundary node; Qold: flow[k-1] at that node; Yprev: storage stage of level
 // k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).
 template <typename R>
-__device__ __noinline__ BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int level, const SecParams<R> sec,
+__device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int level, const SecParams<R> sec,
                                          R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
   BCRow<R> r;
   auto p = [&](int i) { return bc_param(bc, i, reach, B); };
