@@ -41,6 +41,22 @@ __device__ __forceinline__ float frcp(float x) {
   return __builtin_fmaf(r, e, r);
 }
 
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps (r += r/2 (1 - x r^2))
+__device__ __forceinline__ double frsq(double x) {
+  double r = __builtin_amdgcn_rsq(x);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double e = __builtin_fma(-(x * r), r, 1.0);
+    r = __builtin_fma(r * 0.5, e, r);
+  }
+  return r;
+}
+__device__ __forceinline__ float frsq(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  const float e = __builtin_fmaf(-(x * r), r, 1.0f);
+  return __builtin_fmaf(r * 0.5f, e, r);
+}
+
 // x^(-1/3) for x > 0: single-precision log2/exp2 seed y (relative error ~1e-7, so e = 1 - x y^3 ~ 3e-7),
 // then ONE third-order correction y (1 - e)^(-1/3) = y (1 + e/3 + 2 e^2/9 + O(e^3)): the neglected term is
 // ~ (14/81) e^3 < 1e-19, below double rounding (two plain Newton steps cost four more instructions)
@@ -189,7 +205,7 @@ template <typename R> __device__ __forceinline__ R p23_(R x) { return x > R(0) ?
 template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ? x * sqrt_(x) : R(0); }
 
 // conveyance of a single sub-section, hydraulics.py:15-26
-template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) / n; }
+template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) * frcp(n); }
 
 template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA, y13; };
 
@@ -237,24 +253,29 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
     T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
     dPdh = R(2) * sfp;
     const R A_m = A_main + Tb * dfp;                             // :694 (column included)
-    const R R_m = P_main > R(0) ? A_m / P_main : R(0);
-    const R R_l = P_l > R(0) ? A_l / P_l : R(0);
-    const R R_r = P_r > R(0) ? A_r / P_r : R(0);
+    const R R_m = P_main > R(0) ? A_m * frcp(P_main) : R(0);
+    const R R_l = P_l > R(0) ? A_l * frcp(P_l) : R(0);
+    const R R_r = P_r > R(0) ? A_r * frcp(P_r) : R(0);
     const R Kl = conv_(A_l, s.nl, R_l), Km = conv_(A_m, s.nm, R_m), Kr = conv_(A_r, s.nr, R_r);
     K = p23_(p32_(Kl) + p32_(Km) + p32_(Kr));                        // :753
-    g.Rh = P > R(0) ? A / P : R(0);
   } else {
-    g.Rh = P > R(0) ? A / P : R(0);
+    K = R(0);                                                        // set below from Rh
+  }
+  // divisions are reciprocal (v_rcp_f64 + one Newton step, 2e-15) times multiply: an IEEE fp64 divide is ~14
+  // instructions and this function has a dozen of them
+  const R rP = P > R(0) ? frcp(P) : R(0), rT = T > R(0) ? frcp(T) : R(0);
+  g.Rh = A * rP;
+  if (!over) {
     K = conv_(A, s.nm, g.Rh);
-    if (s.compound) K = p23_(p32_(K));                           // the reference's round trip, :747-754
+    if (s.compound) K = p23_(p32_(K));                             // the reference's round trip, :747-754
   }
   const R y13 = g.Rh > R(0) ? rcbrt_pos(g.Rh) : R(0);            // R^(-1/3)
   const R R23 = g.Rh * y13;
   R neq = s.nm;
-  if (s.compound && A > R(0) && g.Rh > R(0) && K > R(0)) neq = A * R23 / K;     // :710-739
-  g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * (R(1) / T))) / (P * P);   // :766-790
+  if (s.compound && A > R(0) && g.Rh > R(0) && K > R(0)) neq = A * R23 * frcp(K);     // :710-739
+  g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * rT)) * (rP * rP);   // :766-790
   g.dKdA = A <= R(0) ? R(0)
-                     : (R23 + A * R(2.0 / 3.0) * y13 * g.dRdA) / neq;                              // :756-764
+                     : (R23 + A * R(2.0 / 3.0) * y13 * g.dRdA) * frcp(neq);                        // :756-764
   g.A = A; g.P = P; g.T = T; g.K = K; g.neq = neq; g.y13 = y13;
   return g;
 }
@@ -270,29 +291,32 @@ template <typename R>
 __device__ __forceinline__ void add_curvature(R curv, R A, R T, R dAdh, R neq, R y13, R dRdA, R h, R Q, R &Se,
                                               R &dSeA, R &eQ) {
   if (curv == R(0)) return;               // ==0 guard for Sc, <=1e-12 guard for its derivatives
-  const R rc = R(1) / curv;
-  const R V = Q / fmax_(A, R(1e-6));                            // hydraulics.py:155-168
-  const R D = A / fmax_(T, R(1e-6));
-  const R Fr = V / sqrt_(R(kG) * fmax_(D, R(1e-6)));
+  // every division below is a reciprocal (2e-15) times a multiplication
+  const R rc = frcp(curv);
+  const R rA = frcp(A), rT = frcp(T);
+  const R V = A > R(1e-6) ? Q * rA : Q * R(1e6);                // Q / max(A, 1e-6), hydraulics.py:155-168
+  const R D = T > R(1e-6) ? A * rT : A * R(1e6);
+  const R Fr = V * frsq(R(kG) * fmax_(D, R(1e-6)));
   const R f = R(8) * R(kG) * neq * neq * y13;                   // 8 g / C^2 with C = R^(1/6)/n, :217-229
-  const R sq = sqrt_(f);
+  const R rsq_f = frsq(f), sq = f * rsq_f;
   const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
   const R den = (R(0.565) + sq) * rc * rc;
-  Se += num / den;                                              // :94-117
+  const R rden = frcp(den);
+  Se += num * rden;                                             // :94-117
   if (fabs_(curv) > R(1e-12)) {
-    const R gD = R(kG) * (A / T);
-    const R Vr = Q / A;
-    const R rs = R(1) / sqrt_(gD), rs3 = rs * rs * rs;          // (gD)^-0.5, (gD)^-1.5
-    const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * (R(1) / T) + (-Q / (A * A)) * rs;
+    const R Vr = Q * rA;
+    const R rs = frsq(R(kG) * (A * rT)), rs3 = rs * rs * rs;    // (gD)^-0.5, (gD)^-1.5
+    const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * rT + (-Q * rA * rA) * rs;
     const R y2 = y13 * y13;
     const R dfA = -(R(8.0 / 3.0)) * R(kG) * neq * neq * (y2 * y2) * dRdA;
-    const R dnum = (R(2.86) / (R(2) * sq) * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
-                   (R(2.86) * sq + R(2.07) * f) * (R(2) * h * (R(1) / T) * Fr * Fr + h * h * R(2) * Fr * dFrA);
-    const R dden = (R(1) / (R(2) * sq) * dfA) * rc * rc;
-    dSeA += (dnum * den - num * dden) / (den * den) * dAdh;     // :119-137, x dA_dh (cross_section.py:164)
-    const R dFrQ = (R(1) / A) * rs;
+    const R half_rsq = R(0.5) * rsq_f;                          // 1 / (2 sqrt f)
+    const R dnum = (R(2.86) * half_rsq * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
+                   (R(2.86) * sq + R(2.07) * f) * (R(2) * h * rT * Fr * Fr + h * h * R(2) * Fr * dFrA);
+    const R dden = (half_rsq * dfA) * rc * rc;
+    dSeA += (dnum * den - num * dden) * (rden * rden) * dAdh;   // :119-137, x dA_dh (cross_section.py:164)
+    const R dFrQ = rA * rs;
     const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
-    eQ += (dnumq * den) / (den * den);                          // :139-153
+    eQ += dnumq * rden;                                         // :139-153
   }
 }
 
@@ -300,13 +324,14 @@ template <typename R>
 __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
   const GeneralProps<R> g = general_props(s, h);
   NodeTerms<R> t;
-  const R iK2 = R(1) / (g.K * g.K);
+  const R rK = frcp(g.K);
+  const R iK2 = rK * rK;
   const R aQ = fabs_(Q);
   const R Sf = Q * aQ * iK2;
-  R dSeA = R(-2) * Sf * (g.dKdA / g.K);   // per unit area
+  R dSeA = R(-2) * Sf * (g.dKdA * rK);   // per unit area
   R Se = Sf, eQ = R(2) * aQ * iK2;
   add_curvature(s.curv, g.A, g.T, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q / g.A;
+  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q * frcp(g.A);
   return t;
 }
 
