@@ -202,7 +202,9 @@ __device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R 
 // x^(2/3), x^(3/2), x^(-1/3) for x >= 0 without pow(): v_log/v_exp seeded x^(-1/3) and v_sqrt
 // (each within a few ulp of the reference's libm pow; 0 -> 0 as 0**p gives in the reference)
 template <typename R> __device__ __forceinline__ R p23_(R x) { return x > R(0) ? x * rcbrt_pos(x) : R(0); }
-template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ? x * sqrt_(x) : R(0); }
+// sqrt(x) for x > 0 as x / sqrt(x) from the reciprocal square root (<= 2e-15; an IEEE fp64 sqrt is ~25 instructions)
+template <typename R> __device__ __forceinline__ R fsqrt_pos(R x) { return x * frsq(x); }
+template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ? x * fsqrt_pos(x) : R(0); }
 
 // conveyance of a single sub-section, hydraulics.py:15-26
 template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) * frcp(n); }
@@ -233,7 +235,7 @@ template <typename R>
 __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) {
   GeneralProps<R> g;
   const R d = fmax_(R(0), h);
-  const R sm = sqrt_(R(1) + s.m * s.m);
+  const R sm = fsqrt_pos(R(1) + s.m * s.m);
   R T = s.b + R(2) * s.m * d;
   R A = (s.b + T) / R(2) * d;
   R P = s.b + R(2) * d * sm;
@@ -243,7 +245,7 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
   if (over) {
     const R dfp = d - s.hbf;
     const R Tb = s.b + R(2) * s.m * s.hbf;
-    const R sfp = sqrt_(R(1) + s.mfp * s.mfp);
+    const R sfp = fsqrt_pos(R(1) + s.mfp * s.mfp);
     const R A_main = (s.b + Tb) / R(2) * s.hbf;                  // :660 (column above omitted)
     const R P_main = s.b + R(2) * s.hbf * sm;
     const R A_l = (s.bl + R(0.5) * s.mfp * dfp) * dfp, P_l = s.bl + dfp * sfp;

@@ -34,6 +34,9 @@ template <typename R> struct PolyView { int lo, hi; bool vl, vr; R xl, xr, zc; }
 
 template <typename R> struct PolyEval { R A, P, Rh, T, neq, K, dRdA, dKdA, dAdh, y13; };
 
+// sqrt that tolerates 0 (a vertical or degenerate edge): x / sqrt(x) via the reciprocal square root
+template <typename R> __device__ __forceinline__ R fsqrt_len(R x) { return x > R(0) ? fsqrt_pos(x) : R(0); }
+
 // contribution of the edge (x0,z0)-(x1,z1) below stage hw; cross_section.py:286-322 edge by edge.
 // dx, dz, len: the edge's extents and full length (an edge that is wet at both ends contributes its
 // whole length whatever the stage, so the square root is shared by the three stages of poly_eval).
@@ -46,24 +49,24 @@ __device__ __forceinline__ void poly_edge(R x0, R z0, R x1, R z1, R dx, R dz, R 
     P += len;
     T += dx;
   } else if (w1 && z0 > hw) {                 // left water's edge, :289-296
-    const R t = (hw - z0) / dz;
+    const R t = (hw - z0) * frcp(dz);
     const R xl = x0 + t * dx;
     const R cx = x1 - xl, cz = z1 - hw;
     A += R(0.5) * d1 * cx;
-    P += sqrt_(cx * cx + cz * cz);
+    P += fsqrt_len(cx * cx + cz * cz);
     T += cx;
   } else if (w0 && z1 > hw) {                 // right water's edge, :298-305
-    const R t = (hw - z0) / dz;
+    const R t = (hw - z0) * frcp(dz);
     const R xr = x0 + t * dx;
     const R cx = xr - x0, cz = hw - z0;
     A += R(0.5) * d0 * cx;
-    P += sqrt_(cx * cx + cz * cz);
+    P += fsqrt_len(cx * cx + cz * cz);
     T += cx;
   }
 }
 
 template <typename R> __device__ __forceinline__ R strip_K(R A, R P, R n) {   // :457-481
-  return (A <= R(0) || P <= R(0)) ? R(0) : conv_(A, n, A / P);
+  return (A <= R(0) || P <= R(0)) ? R(0) : conv_(A, n, A * frcp(P));
 }
 
 // properties / get_equivalent_n / conveyance / dR_dA / dK_dA / dA_dh of one (sub-)section at stage hw
@@ -81,7 +84,7 @@ __device__ __noinline__ PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
     const R x1 = X(j + 1), z1 = Z(j + 1);
     const R dx = x1 - x0, dz = z1 - z0;
     // full length: needed as soon as both ends are wet at the highest of the three stages
-    const R len = (hw + dh > z0 && hw + dh > z1) ? sqrt_(dx * dx + dz * dz) : R(0);
+    const R len = (hw + dh > z0 && hw + dh > z1) ? fsqrt_len(dx * dx + dz * dz) : R(0);
     R eA = 0, eP = 0, eT = 0;
     poly_edge(x0, z0, x1, z1, dx, dz, len, hw, eA, eP, eT);
     A0 += eA; P0 += eP; T0 += eT;
@@ -95,19 +98,21 @@ __device__ __noinline__ PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
   }
   PolyEval<R> e;
   e.A = A0; e.P = P0; e.T = T0;
-  e.Rh = P0 > R(0) ? A0 / P0 : R(0);
+  e.Rh = P0 > R(0) ? A0 * frcp(P0) : R(0);
   e.y13 = e.Rh > R(0) ? rcbrt_pos(e.Rh) : R(0);
   const R R23 = e.Rh * e.y13;
   e.neq = nd.nm;                                                        // :486-487 fallback
   if (A0 > R(0) && P0 > R(0)) {
     const R Kt = p23_(p32_(strip_K(Al, Pl, nd.nl)) + p32_(strip_K(Am, Pm, nd.nm)) + p32_(strip_K(Ar, Pr, nd.nr)));
-    if (Kt > R(0)) e.neq = A0 * R23 / Kt;                               // :492-498
+    if (Kt > R(0)) e.neq = A0 * R23 * frcp(Kt);                         // :492-498
   }
-  e.K = A0 <= R(0) ? R(0) : A0 * R23 / e.neq;                           // :505-513
+  const R rneq = frcp(e.neq);
+  e.K = A0 <= R(0) ? R(0) : A0 * R23 * rneq;                            // :505-513
+  // the two radii differ by ~1e-6 of themselves: these quotients stay IEEE divisions
   const R R1 = P1 > R(0) ? A1 / P1 : R(0), R2 = P2 > R(0) ? A2 / P2 : R(0);
   e.dRdA = (A2 - A1) == R(0) ? R(0) : (R2 - R1) / (A2 - A1);            // :523-531
-  e.dKdA = A0 <= R(0) ? R(0) : (R23 + A0 * R(2.0 / 3.0) * e.y13 * e.dRdA) / e.neq;   // :515-521
-  e.dAdh = (A2 - A1) / (R(2) * dh);                                     // :533-538
+  e.dKdA = A0 <= R(0) ? R(0) : (R23 + A0 * R(2.0 / 3.0) * e.y13 * e.dRdA) * rneq;    // :515-521
+  e.dAdh = (A2 - A1) * R(5.0e5);                                        // / (2 dh), :533-538
   return e;
 }
 
@@ -158,7 +163,7 @@ __device__ __noinline__ NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
           }
           const PolyEval<R> sub = poly_eval(nd, v, hw);
           Ks += p32_(sub.K);                                // :389-390
-          dKs += R(1.5) * sqrt_(sub.K) * sub.dKdA;          // :412-413
+          dKs += R(1.5) * fsqrt_len(sub.K) * sub.dKdA;      // :412-413
         }
         s = -1;
       }
@@ -167,13 +172,13 @@ __device__ __noinline__ NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
     dK = R(2.0 / 3.0) * rcbrt_pos(Ks) * dKs;                // :416
   }
   NodeTerms<R> t;
-  const R iK2 = R(1) / (K * K);
+  const R rK = frcp(K), iK2 = rK * rK;
   const R aQ = fabs_(Q);
   const R Sf = Q * aQ * iK2;
-  R dSeA = R(-2) * Sf * (dK / K);
+  R dSeA = R(-2) * Sf * (dK * rK);
   R Se = Sf, eQ = R(2) * aQ * iK2;
   add_curvature(nd.curv, e.A, e.T, e.dAdh, e.neq, e.y13, e.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eA = dSeA * e.dAdh; t.eQ = eQ; t.v = Q / e.A;
+  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eA = dSeA * e.dAdh; t.eQ = eQ; t.v = Q * frcp(e.A);
   return t;
 }
 
