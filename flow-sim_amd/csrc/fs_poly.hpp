@@ -18,6 +18,15 @@
 #pragma once
 #include "fs_device.hpp"
 
+#ifndef FS_POLY_INLINE
+#define FS_POLY_INLINE 1   // polyline walk inlined into the fold (+37 % on the polyline ensemble): a call inside the Newton loop spills its caller
+#endif
+#if FS_POLY_INLINE
+#define FS_POLY_ATTR __forceinline__
+#else
+#define FS_POLY_ATTR __noinline__
+#endif
+
 namespace fs {
 
 // vertex j of a node lives at x[j * stride], z[j * stride] (vertex-major [P][N] tables: the lanes
@@ -71,7 +80,7 @@ template <typename R> __device__ __forceinline__ R strip_K(R A, R P, R n) {   //
 
 // properties / get_equivalent_n / conveyance / dR_dA / dK_dA / dA_dh of one (sub-)section at stage hw
 template <typename R>
-__device__ __noinline__ PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyView<R> v, R hw) {
+__device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyView<R> v, R hw) {
   const R dh = R(1e-6);
   const int j0 = v.lo - (v.vl ? 1 : 0), j1 = v.hi + (v.vr ? 1 : 0);
   auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : nd.x[(size_t)j * nd.stride]); };
@@ -125,7 +134,7 @@ template <typename R> __device__ __forceinline__ PolyView<R> poly_whole(const Po
 // Se, dSe/dA, dSe/dQ, A, dA/dh of a polyline node: friction_slope / dSf_dA / dSf_dQ of
 // cross_section.py:372-447 (sub-channel sum when >= 2 wetted runs) plus the base-class curvature terms.
 template <typename R>
-__device__ __noinline__ NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
+__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
   const R hw = h + nd.zmin;
   const PolyEval<R> e = poly_eval(nd, poly_whole(nd), hw);
   R K = e.K, dK = e.dKdA;
