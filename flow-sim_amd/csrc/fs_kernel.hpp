@@ -196,9 +196,9 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
 };
 
 // TABLE plus polyline nodes (IrregularSection): per node either a row of the trapezoid table or a
-// polyline; both evaluations stay out of line (fs_poly.hpp walks the vertices in loops).
+// polyline; both evaluations are inlined (FS_POLY_INLINE: out of line they spill the caller around every call).
 template <typename R>
-__device__ __noinline__ NodeTerms<R> node_terms_general_call(const SecParams<R> s, R h, R Q) { return node_terms_general(s, h, Q); }
+__device__ FS_POLY_ATTR NodeTerms<R> node_terms_general_call(const SecParams<R> s, R h, R Q) { return node_terms_general(s, h, Q); }
 
 template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   static constexpr bool kConstT = false;

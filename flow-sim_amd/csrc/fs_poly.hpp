@@ -194,7 +194,7 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
 // normal-depth boundary row at a polyline node: conveyance at hw = z_min + h for the residual,
 // dK/dA * dA/dh at hw = h + bed_level for the derivative (boundary.py:80, :91, :161, :180)
 template <typename R>
-__device__ __noinline__ BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0, R bed, R h, R Q) {
+__device__ FS_POLY_ATTR BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0, R bed, R h, R Q) {
   const R sg = S0 < R(0) ? R(-1) : R(1);
   const R rt = sqrt_(fabs_(S0));
   const PolyEval<R> gr = poly_eval(nd, poly_whole(nd), nd.zmin + h);
