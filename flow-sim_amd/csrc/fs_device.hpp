@@ -19,6 +19,9 @@ constexpr double kG = 9.80665;  // scipy.constants.g (hydraulics.py:2)
 // ---------------------------------------------------------------------------------------------
 // scalar helpers
 // ---------------------------------------------------------------------------------------------
+#ifndef FS_RCP_F32_NR
+#define FS_RCP_F32_NR 0
+#endif
 #ifndef FS_RCP_NR
 #define FS_RCP_NR 1
 #endif
@@ -36,9 +39,13 @@ __device__ __forceinline__ double frcp(double x) {
   return r;
 }
 __device__ __forceinline__ float frcp(float x) {
+#if FS_RCP_F32_NR
   float r = __builtin_amdgcn_rcpf(x);
   float e = __builtin_fmaf(-x, r, 1.0f);
   return __builtin_fmaf(r, e, r);
+#else
+  return __builtin_amdgcn_rcpf(x);          // v_rcp_f32 is accurate to 1 ulp: no Newton step
+#endif
 }
 
 // 1/sqrt(x): v_rsq_f64 seed + two Newton steps (r += r/2 (1 - x r^2))
