@@ -69,7 +69,14 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 1, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),   \
   FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 4)
 
-#ifdef FS_MINIMAL   // experiment builds: just the flagship shapes
+#if defined(FS_MINIMAL) && FS_MINIMAL == 2   // experiment builds: shapes for 512-node trapezoid reaches
+const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false),
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
+#elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),

@@ -685,16 +685,45 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<
 //     M-like row:  pm . d_first + sm . d_last = qm          (d = (dh, dQ))
 // A single cell is a segment (rows = continuity, momentum).  merge() eliminates the node shared by
 // two adjacent segments, pivoting on (M-like row of the left, C-like row of the right): the block
-// row order of the classical Preissmann double sweep, stable for sub-critical flow without
-// pivoting (checked against SuperLU in tests/test_partition_model.py).
+// row order of the classical Preissmann double sweep, no pivoting (checked against SuperLU in
+// tests/test_partition_model.py; see pivot_det below for where the pivot block degenerates).
 // ---------------------------------------------------------------------------------------------
 template <typename R> struct Seg { R pc0, pc1, sc0, sc1, qc, pm0, pm1, sm0, sm1, qm; };
 // what is needed to recover the eliminated node from the two outer ones
 template <typename R> struct Elim { R w10, w11, w20, w21, pm0, pm1, qm, sc0, sc1, qc; };
 
+// Determinant of the pivot block {M-like row of the left segment, C-like row of the right one} at the
+// shared node.  The block is singular where friction balances the celerity terms of a cell - for a wide
+// section roughly at depth h* = (5/3) Se dx, i.e. on grids coarser than the backwater length h/S0
+// (steep, shallow reaches: SURVEY 8d C5 at S0 ~ 9e-4, dx = 500 m, h ~ 0.65 m) - although the system
+// itself is well conditioned there (the reference's SuperLU pivots around it, preissmann.py:139).
+// fp64 rides through: a determinant of relative size d costs log10(1/d) of 16 digits of one Newton
+// step, and the residual stays exact.  fp32 has 7 digits and hits exact zeros about once per 1e6
+// reach-runs (inf -> NaN), so there the pivot entry sm0 is moved until |det| >= 2^-10 of its two
+// products: the elimination is then exact for a Jacobian with one entry perturbed by <= 0.2 %, which
+// Newton absorbs (static pivoting).  Returns det; sm0 is updated in place.
+#ifndef FS_PIVOT_FLOOR_F32
+#define FS_PIVOT_FLOOR_F32 1
+#endif
+__device__ __forceinline__ float abs_mod(float x) { return __builtin_fabsf(x); }     // source modifier, no instruction
+__device__ __forceinline__ double abs_mod(double x) { return __builtin_fabs(x); }
 template <typename R>
-__device__ __forceinline__ void merge(const Seg<R> &A, const Seg<R> &B, Seg<R> &O, Elim<R> &e) {
-  const R det = A.sm0 * B.pc1 - A.sm1 * B.pc0;
+__device__ __forceinline__ R pivot_det(R &sm0, R sm1, R pc0, R pc1) {
+  if (sizeof(R) == 8 || !FS_PIVOT_FLOOR_F32) return sm0 * pc1 - sm1 * pc0;
+  const R t1 = sm0 * pc1, t2 = sm1 * pc0;
+  R det = t1 - t2;
+  const R thr = R(1.0 / 1024.0) * (abs_mod(t1) + abs_mod(t2));
+  if (__builtin_expect(abs_mod(det) < thr, 0)) {
+    det = det < R(0) ? -thr : thr;
+    sm0 = (det + t2) / pc1;          // |t1| ~ |t2| ~ 512 thr here, so pc1 != 0
+  }
+  return det;
+}
+
+template <typename R>
+__device__ __forceinline__ void merge(const Seg<R> &A_, const Seg<R> &B, Seg<R> &O, Elim<R> &e) {
+  Seg<R> A = A_;
+  const R det = pivot_det(A.sm0, A.sm1, B.pc0, B.pc1);
   const R r = frcp(det);
   const R w10 = B.pc1 * r, w11 = -B.pc0 * r;      // D^-1, column of the M-like pivot row
   const R w20 = -A.sm1 * r, w21 = A.sm0 * r;      // D^-1, column of the C-like pivot row

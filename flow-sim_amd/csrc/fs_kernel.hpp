@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 :
             // merge(seg, cell) keeping only what the local back-substitution reads.  The merged M-like row's
             // left part is always a multiple of cell 0's (o.pm = -ga * seg.pm): only the factor kap is carried
             // and recorded, which is one value per node less to park and one multiplication less per merge.
-            const R det = seg.sm0 * cell.pc1 - seg.sm1 * cell.pc0;
+            const R det = pivot_det(seg.sm0, seg.sm1, cell.pc0, cell.pc1);
             const R r = frcp(det);
             LocalElim<R> &e = el[c - 1];
             const R w21 = r * seg.sm0, rs1 = r * seg.sm1;

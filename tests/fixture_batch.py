@@ -86,6 +86,10 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     if mode == "rect_uniform":
         b.set_geometry_uniform([p.geo["b_main"][0] for p in problems], [p.geo["n_main"][0] for p in problems],
                                [p.geo["z_bed"][0] for p in problems], [p.geo["z_bed"][-1] for p in problems])
+    elif mode == "trap_uniform":
+        b.set_geometry_uniform([p.geo["b_main"][0] for p in problems], [p.geo["n_main"][0] for p in problems],
+                               [p.geo["z_bed"][0] for p in problems], [p.geo["z_bed"][-1] for p in problems],
+                               side_slope=[p.geo["m_main"][0] for p in problems])
     elif mode == "irregular":
         b.set_geometry_irregular(p0.geo, n_main_override)
     else:

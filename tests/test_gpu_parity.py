@@ -393,6 +393,65 @@ def test_fp32_rectangular_tracks_the_fp64_reference():
         assert rel_err(Q[:, i], fx["flow"][i], 1.0) <= 5e-4
 
 
+# Reaches of the C5 population (flowsim_amd.synthetic.c5_reach_parameters: seed, global index) on which the
+# fp32 kernels stopped with FS_NAN before the pivot floor existed (fs_device.hpp pivot_det): steep and
+# shallow, uniform flow within a few per cent of the depth h* ~ (5/3) S0 dx at which the unpivoted pivot
+# block {momentum row of cell i, continuity row of cell i+1} is singular.  The first one starts exactly
+# there (det == 0 in fp32 in every cell of the initial state, whatever the build); the others met an
+# exact zero later in the run in one build or another.
+SINGULAR_PIVOT_REACHES = [(4, 506130), (9, 111108), (3, 154763), (3, 180059), (3, 628857), (6, 722298),
+                          (10, 1010160), (20260214, 89004), (20260214, 163455), (9, 848778), (9, 972785)]
+
+
+def _singular_pivot_problems(N, n_steps, tol):
+    from flowsim_amd.synthetic import c5_reach_parameters
+    from synth import trap_problem
+    probs = []
+    for seed, idx in SINGULAR_PIVOT_REACHES:
+        b, m, n, S0, Qb = (float(v[0]) for v in c5_reach_parameters(idx, 1, seed))
+        probs.append(trap_problem(b, m, n, S0, Qb, N, n_steps, tol=tol))
+    return probs
+
+
+@pytest.mark.parametrize("shape", ["8,1", "16,4"])
+def test_fp32_rides_through_a_singular_pivot_block(shape, monkeypatch):
+    """fp32, 512 nodes, the whole hydrograph: every reach converges at every level (static pivoting,
+    pivot_det) and stays within 5e-3 of the fp64 run of the same reach (the fp32 mode stops Newton at a
+    residual norm of 1e-3)."""
+    from fixture_batch import batch_from_problems
+    monkeypatch.setenv("FS_KERNEL_SHAPE", shape)
+    n_steps = 36
+    out = {}
+    for dtype, tol in (("f64", 1e-6), ("f32", 1e-3)):
+        probs = _singular_pivot_problems(512, n_steps, tol)
+        with batch_from_problems(probs, mode="trap_uniform", dtype=dtype, history=False) as b:
+            for k in (4, n_steps - 4):             # two launches, as bench.py runs it
+                b.step(k)
+            assert np.all(b.status() == 0), (dtype, b.status())
+            out[dtype] = (b.hydrographs(), b.iterations(1, n_steps))
+    assert out["f32"][1].max() <= 5 and out["f64"][1].max() <= 6
+    hy32, hy64 = out["f32"][0], out["f64"][0]
+    assert np.max(np.abs(hy32 - hy64) / np.maximum(np.abs(hy64), 1e-3)) <= 5e-3
+
+
+def test_fp64_near_singular_pivot_block_against_the_c_oracle():
+    """The same reaches in fp64 against the partially pivoted banded LU of the C oracle: the unpivoted
+    elimination loses digits of a Newton step there, not of the converged level."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle
+    probs = _singular_pivot_problems(200, 6, 1e-6)
+    with batch_from_problems(probs, mode="trap_uniform") as b:
+        b.step(6)
+        assert np.all(b.status() == 0)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    for i, p in enumerate(probs):
+        ref = c_oracle.run(p)
+        assert rel_err(h[:, i], ref["depth"], 1e-3) <= TOL, SINGULAR_PIVOT_REACHES[i]
+        assert rel_err(Q[:, i], ref["flow"], 1.0) <= TOL, SINGULAR_PIVOT_REACHES[i]
+        assert np.array_equal(its[:, i], ref["iters"]), SINGULAR_PIVOT_REACHES[i]
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (65 536 reaches x 4 096 nodes, fp64) through size-independent
     properties: (i) 256 distinct channels replicated 256 times give bitwise identical copies,
