@@ -452,6 +452,28 @@ def test_fp64_near_singular_pivot_block_against_the_c_oracle():
         assert np.array_equal(its[:, i], ref["iters"]), SINGULAR_PIVOT_REACHES[i]
 
 
+def test_flow_regime_grid_against_the_c_oracle():
+    """Bed slope x spatial step x base flow, from backwater-resolved grids (h / h* = 250) to kinematic ones
+    (h / h* = 0.02, Froude up to 0.8): the unpivoted tree elimination against partially pivoted LU on both
+    sides of the depth h* where its pivot block changes sign (tools/scan_regimes.py prints the table)."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle
+    from synth import trap_problem
+    for S0 in (1e-4, 1e-3, 5e-3):
+        for dx in (100.0, 500.0, 2000.0):
+            for q in (0.3, 1.0, 4.0):
+                p = trap_problem(40.0, 2.0, 0.03, S0, q * 40.0, 130, 4, dx=dx)
+                ref = c_oracle.run(p)
+                with batch_from_problems([p], mode="trap_uniform") as b:
+                    b.step(4)
+                    assert b.status()[0] == 0 and ref["status"] == 0, (S0, dx, q)
+                    h, Q = b.history_arrays()
+                    its = b.iterations()[:, 0]
+                assert rel_err(h[:, 0], ref["depth"], 1e-3) <= TOL, (S0, dx, q)
+                assert rel_err(Q[:, 0], ref["flow"], 1.0) <= TOL, (S0, dx, q)
+                assert np.array_equal(its, ref["iters"]), (S0, dx, q)
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (65 536 reaches x 4 096 nodes, fp64) through size-independent
     properties: (i) 256 distinct channels replicated 256 times give bitwise identical copies,
