@@ -1,4 +1,5 @@
-"""Debug aid: run the C5 workload (trapezoid + power rating curve) with the residual trace on, list the reaches
+"""Debug aid: run the C5 workload (trapezoid + power rating curve; --workload c3: rectangular + normal depth,
+--dx / --dt to move the population across regimes) with the residual trace on, list the reaches
 whose status is not FS_OK and replay each alone (B = 1, same parameters) - with the kernel shape and
 library taken from FS_KERNEL_SHAPE / FS_LIB as usual.
 usage: python tools/find_bad_reach.py [--dtype f32] [--nodes 512] [--reaches 131072] [--split 4,32] [--only IDX]"""
@@ -7,19 +8,29 @@ import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "flow-sim_amd"))
 from flowsim_amd import BoundarySpec, PreissmannBatch
 from flowsim_amd import _abi as A
-from flowsim_amd.synthetic import C5_SEED, c5_reach_parameters, inflow_table, normal_depth_trap
+from flowsim_amd.synthetic import C5_SEED, c3_reach_parameters, c5_reach_parameters, inflow_table, normal_depth_rect, normal_depth_trap
 
 
 def run(first, B, N, levels, dtype, trace, split, seed=C5_SEED):
-    theta, dt, dx = 0.6, 1800.0, 500.0
+    theta, dt, dx = 0.6, a.dt, a.dx
     tol = 1e-3 if dtype == "f32" else 1e-6
-    b_, m_, n_, S0, Qb = c5_reach_parameters(first, B, seed)
-    hn = normal_depth_trap(b_, m_, n_, S0, Qb)
-    batch = PreissmannBatch(B, N, levels, dtype=dtype, section_mode="trap_uniform", trace=trace)
+    if a.workload == "c5":
+        b_, m_, n_, S0, Qb = c5_reach_parameters(first, B, seed)
+        hn = normal_depth_trap(b_, m_, n_, S0, Qb)
+    else:
+        b_, n_, S0, Qb = c3_reach_parameters(first, B, seed)
+        m_ = np.zeros(B)
+        hn = normal_depth_rect(b_, n_, S0, Qb)
+    batch = PreissmannBatch(B, N, levels, dtype=dtype, section_mode="trap_uniform" if a.workload == "c5" else "rect_uniform",
+                            trace=trace)
     batch.set_scheme(theta, dt, dx, tol, 100)
-    batch.set_geometry_uniform(b_, n_, S0 * (N - 1) * dx, np.zeros(B), side_slope=m_)
-    batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_RATING_POWER, dict(a=Qb / hn ** 1.6, b=np.full(B, 1.6),
-                                                                        stage_shift=np.zeros(B), bed_level=np.zeros(B))))
+    if a.workload == "c5":
+        batch.set_geometry_uniform(b_, n_, S0 * (N - 1) * dx, np.zeros(B), side_slope=m_)
+        batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_RATING_POWER, dict(a=Qb / hn ** 1.6, b=np.full(B, 1.6),
+                                                                            stage_shift=np.zeros(B), bed_level=np.zeros(B))))
+    else:
+        batch.set_geometry_uniform(b_, n_, S0 * (N - 1) * dx, np.zeros(B))
+        batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
     batch.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, levels, dt)))
     batch.set_state_uniform(hn, Qb)
     for k in split:
@@ -28,6 +39,8 @@ def run(first, B, N, levels, dtype, trace, split, seed=C5_SEED):
 
 
 ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="c5", choices=["c5", "c3"])
+ap.add_argument("--dx", type=float, default=500.0); ap.add_argument("--dt", type=float, default=1800.0)
 ap.add_argument("--dtype", default="f32"); ap.add_argument("--nodes", type=int, default=512)
 ap.add_argument("--reaches", type=int, default=131072)
 ap.add_argument("--only", type=int, default=-1)
@@ -42,7 +55,7 @@ if a.only < 0:
     batch, par = run(0, a.reaches, a.nodes, levels, a.dtype, False, split, a.seed)
     st = batch.status(); its = batch.iterations(1, a.steps)
     bad = np.nonzero(st)[0]
-    print("kernel", batch.kernel_info(), "bad reaches", bad[:16], "status", st[bad][:16])
+    print("kernel", batch.kernel_info(), "iterations mean %.4f max %d" % (its.mean(), its.max()), "bad reaches", bad[:16], "status", st[bad][:16])
     batch.close()
 else:
     bad = np.array([a.only])
