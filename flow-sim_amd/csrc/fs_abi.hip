@@ -32,19 +32,21 @@ struct Shape { int M, W; };
 typedef void (*LaunchFn)(const void *args, int B, hipStream_t st);
 typedef const void *KernelPtr;
 
-template <typename R, int SEC, int M, int W, bool RAGGED, bool BCFAST>
+template <typename R, int SEC, int M, int W, bool RAGGED, int BCK>
 void launch_(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCFAST>), dim3(B), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
 // full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
-// bcfast == 1: boundary rows inlined, valid only for RECT_UNIFORM with bc_is_light() kinds on both ends
-struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
+// bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): 0 any, 1 RECT_UNIFORM with
+//      bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
+struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
+#define FS_BCK(kind) (2 + (kind))
 
-#define FS_ENTRY_X(R, DT, SEC, M, W, FULL, FAST)                        \
-  { DT, SEC, M, W, FULL, FAST, &launch_<R, SEC, M, W, !(FULL), FAST>,   \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), FAST> }
+#define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK)                              \
+  { DT, SEC, M, W, FULL, (int)(BCK), &launch_<R, SEC, M, W, !(FULL), (int)(BCK)>,   \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> }
 #define FS_ENTRY(R, DT, SEC, M, W) FS_ENTRY_X(R, DT, SEC, M, W, 0, false)
 
 #define FS_ENTRIES(R, DT)                                                                         \
@@ -61,9 +63,19 @@ struct Entry { int dtype, sec, M, W, full, bcfast; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1),          \
   FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1),          \
   FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 16, 4),  \
+  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)),                     \
+  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_RATING_POWER)),                     \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
+// downstream kind known at compile time, fp64 (gerd_roseires-like channels: ~100 nodes, gate curve or normal depth)
+#define FS_ENTRIES_TABLE_PINNED                                                                   \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 1, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 1, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH)),                    \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH)),                    \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 4, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 4, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
 // polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
 #define FS_ENTRIES_IRREGULAR                                                                      \
   FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 1, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),   \
@@ -84,27 +96,35 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),
                           FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),
+                          FS_ENTRIES_TABLE_PINNED,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)};
 #else
-const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_IRREGULAR};
+const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_TABLE_PINNED, FS_ENTRIES_IRREGULAR};
 #endif
 
-const Entry *pick_kernel(int dtype, int sec, int N, bool light_bc, std::string *why) {
+// usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
+// choice for experiments and tests.
+const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, std::string *why) {
   const int cells = N - 1;
   int wantM = 0, wantW = 0;
   if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
+  const char *gen = std::getenv("FS_KERNEL_GENERAL");
+  const bool general_only = gen && gen[0] == '1';
+  const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const Entry *best = nullptr;
   for (const Entry &e : kEntries) {
     if (e.dtype != dtype || e.sec != sec) continue;
     const int cap = 64 * e.W * e.M;
     if (cap < cells) continue;
     if (e.full && !(cells == cap || cells == cap - 1)) continue;
-    if (e.bcfast && (!light_bc || sec != FS_SEC_RECT_UNIFORM)) continue;
+    if (e.bck == 1 && (!light || sec != FS_SEC_RECT_UNIFORM)) continue;
+    if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2 || general_only)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
-    // smallest capacity first; on ties prefer fewer waves per reach, then the select-free variant
+    // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
+    const int spec = e.full + (e.bck != 0), bspec = best ? best->full + (best->bck != 0) : 0;
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
-        (e.M == best->M && e.W == best->W && e.full + e.bcfast > best->full + best->bcfast))
+        (e.M == best->M && e.W == best->W && spec > bspec))
       best = &e;
   }
   if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4097 nodes)";
@@ -229,7 +249,7 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     return nullptr;
   }
   std::string why;
-  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, true, &why);
+  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, FS_BC_FLOW_HYDROGRAPH, FS_BC_FLOW_HYDROGRAPH, &why);
   if (!k) { fail("fs_batch_create: " + why); return nullptr; }
   fs_batch *b = new fs_batch();
   b->d = *desc;
@@ -456,8 +476,7 @@ int fs_batch_step(fs_batch *b, int32_t n_steps) {
   if (b->level + n_steps >= b->d.max_levels) return fail("fs_batch_step: would run past max_levels");
   HIP_TRY(hipSetDevice(b->d.device));
   {   // the boundary kinds are known now: prefer the variant with inlined boundary rows
-    const bool light = fs::bc_is_light(b->bc_kind[0]) && fs::bc_is_light(b->bc_kind[1]);
-    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, light, nullptr);
+    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1], nullptr);
     if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
     b->kern = k;
   }

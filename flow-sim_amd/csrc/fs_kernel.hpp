@@ -22,7 +22,11 @@
 // Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
 // RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
 // padding and the per-cell padding selects (and their 64-bit lane masks) disappear;
-// BCFAST = true (RECT_UNIFORM only) inlines the boundary rows and requires bc_is_light() kinds.
+// BCK (boundary-kind class the kernel is compiled for): 0 = any kinds (the row evaluation switches at run time),
+// 1 = RECT_UNIFORM with bc_is_light() kinds on both ends (closed-form rows, parameters in LDS), 2 + k = flow
+// hydrograph upstream and kind k downstream, known at compile time: the switch over the nine kinds folds
+// away and with it a third of the registers of the general-section kernels (C5 +10 % fp32 / +25 % fp64,
+// C4 +20 %).  fs_abi.hip picks the most specific instantiation that matches the batch.
 #pragma once
 #include <type_traits>
 #include "fs_device.hpp"
@@ -34,6 +38,9 @@
 #endif
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
+#endif
+#ifndef FS_WPE_PINNED_SHORT
+#define FS_WPE_PINNED_SHORT 2   // fp64, one wave per reach, <= 2 cells per lane, boundary kinds fixed at compile time
 #endif
 #ifndef FS_WPE_W1_F32
 #define FS_WPE_W1_F32 2    // the same for fp32: two waves per SIMD fit (<= 256 registers) and hide the tree's latency (C5 fp32 +18 %)
@@ -116,14 +123,22 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
     s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
     return s;
   }
-  template <bool BCFAST>
+  template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    if (BCFAST)   // bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only)
+    if (BCK == 1)   // bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only)
       return bc_eval_rect(bc, (LdsParams<R>)bc.params, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
-    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
+
+// the descriptor with its kind pinned to what the instantiation was compiled for (BCK >= 2)
+template <int BCK, int SIDE, typename R>
+__device__ __forceinline__ BCDesc<R> pinned(const BCDesc<R> &bc) {
+  BCDesc<R> d = bc;
+  if (BCK >= 2) d.kind = SIDE == 0 ? (int)FS_BC_FLOW_HYDROGRAPH : BCK - 2;
+  return d;
+}
 
 template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   static constexpr bool kConstT = false;
@@ -151,10 +166,10 @@ template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
     s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
     return s;
   }
-  template <bool BCFAST>
+  template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -188,10 +203,10 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
     return node_terms_general(section(node), h, Q);
   }
-  template <bool BCFAST>
+  template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -227,9 +242,10 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     if (pn[node] > 0) return node_terms_poly(poly(node), h, Q);
     return node_terms_general_call(section(node), h, Q);
   }
-  template <bool BCFAST>
-  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
+  template <int BCK, int SIDE>
+  __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc_, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
+    const BCDesc<R> bc = pinned<BCK, SIDE>(bc_);
     if (pn[node] > 0 && bc.kind == FS_BC_NORMAL_DEPTH)
       return bc_normal_depth_poly(poly(node), bc_param(bc, 0, reach, B), bc_param(bc, 1, reach, B), h, Q);
     if (pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
@@ -266,8 +282,8 @@ template <typename R, int M, int W> struct Smem {
 // residual is kept in qc.
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
-template <typename R, int SEC, int M, int W, bool RAGGED = true, bool BCFAST = false>
-__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : FS_WPE_W1) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
+template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
+__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : FS_WPE_W1)) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;
@@ -472,7 +488,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 :
       // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
-        const BCRow<R> U = geo.template boundary<BCFAST>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        const BCRow<R> U = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
         sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
         nrm2 += U.res * U.res;
       }
@@ -481,7 +497,7 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 :
         int flag = 0;
 #pragma unroll
         for (int j = kJD0; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        const BCRow<R> Dn = geo.template boundary<BCFAST>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        const BCRow<R> Dn = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
         nrm2 += Dn.res * Dn.res;
         if (flag) sm.xflag[parity] = flag;

@@ -439,7 +439,7 @@ def test_fp64_near_singular_pivot_block_against_the_c_oracle():
     elimination loses digits of a Newton step there, not of the converged level."""
     from fixture_batch import batch_from_problems
     from oracle import c_oracle
-    probs = _singular_pivot_problems(200, 6, 1e-6)
+    probs = _singular_pivot_problems(500, 6, 1e-6)     # 8 cells per lane, ragged, rating-curve instantiation
     with batch_from_problems(probs, mode="trap_uniform") as b:
         b.step(6)
         assert np.all(b.status() == 0)
@@ -472,6 +472,34 @@ def test_flow_regime_grid_against_the_c_oracle():
                 assert rel_err(h[:, 0], ref["depth"], 1e-3) <= TOL, (S0, dx, q)
                 assert rel_err(Q[:, 0], ref["flow"], 1.0) <= TOL, (S0, dx, q)
                 assert np.array_equal(its, ref["iters"]), (S0, dx, q)
+
+
+@pytest.mark.parametrize("case", ["trap_512", "trap_500", "gerd", "bc_compound_normal"])
+def test_kernels_compiled_for_a_boundary_pair_match_the_general_ones(case, monkeypatch):
+    """Instantiations with the downstream kind fixed at compile time (BCK >= 2, fs_kernel.hpp) against the
+    general kernels of the same shape (FS_KERNEL_GENERAL=1): same rows, same source - equal iteration counts,
+    hydrographs equal to a few ulp (the compiler contracts a row inlined next to one kind differently from
+    the same row next to nine), and fewer registers (which is the point of them)."""
+    from fixture_batch import batch_from_problems
+    if case.startswith("trap"):
+        probs = _singular_pivot_problems(int(case[5:]), 5, 1e-6)[:4]
+        mode = "trap_uniform"
+    else:
+        _, _, probs = problems_of(os.path.join(GOLDEN, case + ".npz"))
+        probs, mode = probs[:1], "table"
+    monkeypatch.setenv("FS_KERNEL_SHAPE", "8,1" if mode == "trap_uniform" else "2,1")
+    n = min(probs[0].nt - 1, 6)
+    out = []
+    for general in ("1", "0"):
+        monkeypatch.setenv("FS_KERNEL_GENERAL", general)
+        with batch_from_problems(probs, mode=mode, history=False) as b:
+            b.step(n)
+            assert np.all(b.status() == 0)
+            out.append((b.hydrographs(), b.iterations(), b.kernel_info()))
+    (hy_g, it_g, k_g), (hy_p, it_p, k_p) = out
+    assert k_p["vgprs"] < k_g["vgprs"], (k_g, k_p)          # a different kernel did run
+    assert np.array_equal(it_g, it_p)
+    assert np.max(np.abs(hy_g - hy_p) / np.maximum(np.abs(hy_g), 1e-3)) <= 1e-13
 
 
 def test_full_size_batch_properties():
