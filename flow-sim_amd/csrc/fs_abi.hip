@@ -39,8 +39,8 @@ void launch_(const void *args, int B, hipStream_t st) {
 }
 
 // full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
-// bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): 0 any, 1 RECT_UNIFORM with
-//      bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
+// bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
+//      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
 struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
 #define FS_BCK(kind) (2 + (kind))
 
@@ -67,19 +67,16 @@ struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_RATING_POWER)),                     \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
   FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
-  FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4)
-// downstream kind known at compile time, fp64 (gerd_roseires-like channels: ~100 nodes, gate curve or normal depth)
-#define FS_ENTRIES_TABLE_PINNED                                                                   \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 1, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 1, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH)),                    \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH)),                    \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 4, 1, 0, FS_BCK(FS_BC_RATING_BLEND)),                    \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_TABLE, 4, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
+  FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4),                        \
+  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 1, 1, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 2, 1, 0, -1),      \
+  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 4, 1, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 1, 0, -1),      \
+  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 2, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 4, 0, -1)
 // polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
 #define FS_ENTRIES_IRREGULAR                                                                      \
   FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 1, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),   \
-  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 4)
+  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 4),   \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, -1), FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, -1), \
+  FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1), FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)
 
 #if defined(FS_MINIMAL) && FS_MINIMAL == 2   // experiment builds: shapes for 512-node trapezoid reaches
 const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
@@ -96,11 +93,10 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),
                           FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),
-                          FS_ENTRIES_TABLE_PINNED,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)};
 #else
-const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_TABLE_PINNED, FS_ENTRIES_IRREGULAR};
+const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_IRREGULAR};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
@@ -118,11 +114,13 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, std::strin
     const int cap = 64 * e.W * e.M;
     if (cap < cells) continue;
     if (e.full && !(cells == cap || cells == cap - 1)) continue;
+    if (e.bck == 0 && (usk == FS_BC_STORAGE_CURVE || dsk == FS_BC_STORAGE_CURVE)) continue;
     if (e.bck == 1 && (!light || sec != FS_SEC_RECT_UNIFORM)) continue;
     if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2 || general_only)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
-    const int spec = e.full + (e.bck != 0), bspec = best ? best->full + (best->bck != 0) : 0;
+    auto rank = [](const Entry &x) { return x.full + (x.bck >= 1 ? 2 : x.bck == 0 ? 1 : 0); };
+    const int spec = rank(e), bspec = best ? rank(*best) : 0;
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
         (e.M == best->M && e.W == best->W && spec > bspec))
       best = &e;
@@ -477,6 +475,8 @@ int fs_batch_step(fs_batch *b, int32_t n_steps) {
   HIP_TRY(hipSetDevice(b->d.device));
   {   // the boundary kinds are known now: prefer the variant with inlined boundary rows
     const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1], nullptr);
+    if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
+      return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
     if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
     b->kern = k;
   }

@@ -530,7 +530,9 @@ __host__ __device__ inline bool bc_is_storage(int kind) { return kind == FS_BC_S
 
 // sec: section of the boundary node; Qold: flow[k-1] at that node; Yprev: storage stage of level
 // k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).
-template <typename R>
+// WITH_SC = false compiles the general storage row out (kernels of boundary class 0, fs_kernel.hpp): it is the one
+// row with an out-of-line call (the Brent iteration), which costs every caller 90-130 registers and its scratch.
+template <bool WITH_SC = true, typename R>
 __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int level, const SecParams<R> sec,
                                          R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
   BCRow<R> r;
@@ -587,6 +589,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
       r.dq = R(0) - (Y <= ymin ? R(0) : R(1) / area) * R(0.5) * dt;     // boundary.py:213-237
     } break;
     case FS_BC_STORAGE_CURVE: {
+      if (!WITH_SC) { r.res = R(0); r.dh = R(1); r.dq = R(0); break; }      // never launched (fs_abi.hip: pick_kernel)
       const R bed = p(FS_SC_BED_LEVEL);
       return bc_storage_curve(bc, reach, B, level, entry_props(general_props_call(sec, h)),
                               entry_props(general_props_call(sec, h + bed - sec.z)), h, Q, Qold, dt, Yprev, Ynew, flag);

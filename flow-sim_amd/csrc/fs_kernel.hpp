@@ -22,7 +22,8 @@
 // Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
 // RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
 // padding and the per-cell padding selects (and their 64-bit lane masks) disappear;
-// BCK (boundary-kind class the kernel is compiled for): 0 = any kinds (the row evaluation switches at run time),
+// BCK (boundary-kind class the kernel is compiled for): -1 = any kinds, 0 = any but FS_BC_STORAGE_CURVE (the row
+// evaluation switches at run time),
 // 1 = RECT_UNIFORM with bc_is_light() kinds on both ends (closed-form rows, parameters in LDS), 2 + k = flow
 // hydrograph upstream and kind k downstream, known at compile time: the switch over the nine kinds folds
 // away and with it a third of the registers of the general-section kernels (C5 +10 % fp32 / +25 % fp64,
@@ -39,8 +40,11 @@
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
 #endif
+#ifndef FS_WPE_LEAN_SHORT
+#define FS_WPE_LEAN_SHORT 2     // fp64 table kernels of class 0 with <= 2 cells per lane: 314 registers capped at 256, two waves per SIMD (C4 +43 %)
+#endif
 #ifndef FS_WPE_PINNED_SHORT
-#define FS_WPE_PINNED_SHORT 2   // fp64, one wave per reach, <= 2 cells per lane, boundary kinds fixed at compile time
+#define FS_WPE_PINNED_SHORT 2   // the same for kernels with the boundary kinds fixed at compile time
 #endif
 #ifndef FS_WPE_W1_F32
 #define FS_WPE_W1_F32 2    // the same for fp32: two waves per SIMD fit (<= 256 registers) and hide the tree's latency (C5 fp32 +18 %)
@@ -128,7 +132,7 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
     if (BCK == 1)   // bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only)
       return bc_eval_rect(bc, (LdsParams<R>)bc.params, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
-    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval<BCK != 0>(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -169,7 +173,7 @@ template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval<BCK != 0>(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -206,7 +210,7 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    return bc_eval(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval<BCK != 0>(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -248,14 +252,14 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     const BCDesc<R> bc = pinned<BCK, SIDE>(bc_);
     if (pn[node] > 0 && bc.kind == FS_BC_NORMAL_DEPTH)
       return bc_normal_depth_poly(poly(node), bc_param(bc, 0, reach, B), bc_param(bc, 1, reach, B), h, Q);
-    if (pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
+    if (BCK != 0 && pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
       const PolyNode<R> nd = poly(node);
       const PolyEval<R> er = poly_eval(nd, poly_whole(nd), nd.zmin + h);
       const PolyEval<R> ed = poly_eval(nd, poly_whole(nd), h + bc_param(bc, FS_SC_BED_LEVEL, reach, B));
       EntryProps<R> pr{er.A, er.Rh, er.neq, er.dRdA, er.dAdh}, pd{ed.A, ed.Rh, ed.neq, ed.dRdA, ed.dAdh};
       return bc_storage_curve(bc, reach, B, level, pr, pd, h, Q, Qold, dt, Yprev, Ynew, flag);
     }
-    return bc_eval(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
+    return bc_eval<BCK != 0>(bc, reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
 
@@ -283,7 +287,7 @@ template <typename R, int M, int W> struct Smem {
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
 template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
-__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : FS_WPE_W1)) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : FS_WPE_W1))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;

@@ -44,6 +44,10 @@ class PreissmannSolver(Solver):
         rect = ("irr_npts" not in geo and np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)
                 and np.ptp(geo["b_main"]) == 0 and np.ptp(geo["n_main"]) == 0 and ch.input_xs is not None
                 and len(ch.input_xs) == 2)
+        us_spec = boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step)
+        ds_spec = boundary_to_spec(ch.downstream_boundary, max(nt, 2), self.time_step)
+        # the general reservoir row is compiled into the table / polyline kernels only
+        rect = rect and A.BC_STORAGE_CURVE not in (us_spec.kind, ds_spec.kind)
         poly = "irr_npts" in geo                   # any IrregularSection node (cross_section.py:207-543)
         mode = "irregular" if poly else ("rect_uniform" if rect else "table")
         with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode=mode, history=True, trace=(verbose == 3)) as b:
@@ -54,8 +58,8 @@ class PreissmannSolver(Solver):
                 b.set_geometry_irregular(geo)
             else:
                 b.set_geometry_table(geo)
-            b.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step))
-            b.set_boundary(A.DOWNSTREAM, boundary_to_spec(ch.downstream_boundary, max(nt, 2), self.time_step))
+            b.set_boundary(A.UPSTREAM, us_spec)
+            b.set_boundary(A.DOWNSTREAM, ds_spec)
             b.set_state(ch.initial_conditions[:, 0], ch.initial_conditions[:, 1])
             if nt > 1:
                 b.step(nt - 1)

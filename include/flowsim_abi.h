@@ -84,7 +84,9 @@ enum {
                                  the FS_SC_* scalars, then stage[n_curve], area[n_curve] of set_area_curve
                                  (n_curve = 0: constant surface_area).  The mass-balance root
                                  (lumped_storage.py:24-35) is found on the device with the algorithm of
-                                 scipy.optimize.brentq and its default tolerances. */
+                                 scipy.optimize.brentq and its default tolerances.  Section modes
+                                 FS_SEC_TABLE and FS_SEC_IRREGULAR only (fs_batch_step refuses it in the
+                                 uniform-geometry modes: describe such a channel as a table). */
 };
 /* scalar slots of FS_BC_STORAGE_CURVE */
 enum {

@@ -75,7 +75,8 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     p0 = problems[0]
     B = len(problems)
     if mode == "auto":
-        mode = "rect_uniform" if all(is_rect_uniform(p) for p in problems) else "table"
+        general_storage = any(boundary_spec(bc, p0.nt).kind == A.BC_STORAGE_CURVE for bc in (p0.us, p0.ds))
+        mode = "rect_uniform" if all(is_rect_uniform(p) for p in problems) and not general_storage else "table"
         if "irr_npts" in p0.geo and np.any(p0.geo["irr_npts"] > 0):
             mode = "irregular"
         if mode != "rect_uniform" and B > 1:
