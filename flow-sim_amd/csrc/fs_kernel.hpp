@@ -40,6 +40,12 @@
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
 #endif
+#ifndef FS_SHARE_NODE
+#define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
+#endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
+#ifndef FS_WPE_LEAN_POLY
+#define FS_WPE_LEAN_POLY 2      // the same for the polyline kernels (332 registers capped at 256: +79 % on the polyline ensemble)
+#endif
 #ifndef FS_WPE_LEAN_SHORT
 #define FS_WPE_LEAN_SHORT 2     // fp64 table kernels of class 0 with <= 2 cells per lane: 314 registers capped at 256, two waves per SIMD (C4 +43 %)
 #endif
@@ -287,7 +293,7 @@ template <typename R, int M, int W> struct Smem {
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
 template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
-__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : FS_WPE_W1))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR ? FS_WPE_LEAN_POLY : FS_WPE_W1)))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;
@@ -319,11 +325,24 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 :
   // level-k constants of the 4-point stencil from the accepted state (h, Q) of level k:
   //   C = [sumA]/(2dt) + cq*dQ                 + kc0
   //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + g*(hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)
+  // Node s0 + M is lane + 1's node s0 (both lanes hold bitwise equal copies of its unknowns): with one wave per reach the
+  // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding cell ever looks at
+  // (and discards) unless the reach fills the wave exactly - then lane 63 evaluates its last node itself.
+  constexpr bool kShareNode = FS_SHARE_NODE && W == 1 && !Geo::kConstT;
+  auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) {
+    auto rol = [](R v) { return dpp_mov<0x134>(v); };     // wave_rol:1
+    NodeTerms<R> r;
+    r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eA = rol(first.eA); r.eQ = rol(first.eQ); r.v = rol(first.v);
+    if (NC == 64 * M && lane == 63) r = geo.terms(N - 1, hM, QM);
+    return r;
+  };
   auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
     NodeTerms<R> L = geo.terms(min(s0, N - 1), hh[0], QQ[0]);
+    NodeTerms<R> Rlast;
+    if (kShareNode) Rlast = last_node_terms(L, hh[M], QQ[M]);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
+      const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
       const R sumA = L.A + Rn.A;
       sm.kc[0][c][t] = -sumA * r2dt + cqk * (QQ[c + 1] - QQ[c]);
       sm.kc[1][c][t] = -(QQ[c + 1] + QQ[c]) * r2dt + cqk * (QQ[c + 1] * Rn.v - QQ[c] * L.v);
@@ -417,12 +436,14 @@ __global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 :
       R nrm2 = R(0);
       {
         NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+        NodeTerms<R> Rlast;
+        if (kShareNode) Rlast = last_node_terms(L, h[M], Q[M]);
         if (!Geo::kConstT) Tn[0] = L.T;
         R kap = R(1);                      // the M-like row keeps the direction of cell 0's: pm = kap * (pf0, pf1)
 #pragma unroll
         for (int c = 0; c < M; ++c) {
           const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
-          const NodeTerms<R> Rn = geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+          const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
           if (!Geo::kConstT) Tn[c + 1] = Rn.T;
           Seg<R> cell;
           {
