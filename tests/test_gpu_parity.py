@@ -480,6 +480,27 @@ def test_fp64_near_singular_pivot_block_against_the_c_oracle():
         assert np.array_equal(its[:, i], ref["iters"]), SINGULAR_PIVOT_REACHES[i]
 
 
+@pytest.mark.parametrize("N", [2, 64, 65, 66, 128, 129, 130, 257, 513])
+def test_trapezoid_reaches_that_fill_the_wave_exactly(N):
+    """General-section kernels take a lane's last node from its right neighbour (FS_SHARE_NODE); lane 63 has none
+    and evaluates the node itself when the reach fills the wave to the last cell (N - 1 = 64 M), one cell
+    less leaves a padding cell there, one more moves to the next shape."""
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle
+    from synth import trap_problem
+    probs = [trap_problem(30.0 + 10 * i, 1.5, 0.03, 4e-4, 60.0 + 25 * i, N, 4, dt=900.0, dx=400.0) for i in range(3)]
+    with batch_from_problems(probs, mode="trap_uniform") as b:
+        b.step(4)
+        assert np.all(b.status() == 0)
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    for i, p in enumerate(probs):
+        ref = c_oracle.run(p)
+        assert rel_err(h[:, i], ref["depth"], 1e-3) <= TOL, N
+        assert rel_err(Q[:, i], ref["flow"], 1.0) <= TOL, N
+        assert np.array_equal(its[:, i], ref["iters"]), N
+
+
 def test_flow_regime_grid_against_the_c_oracle():
     """Bed slope x spatial step x base flow, from backwater-resolved grids (h / h* = 250) to kinematic ones
     (h / h* = 0.02, Froude up to 0.8): the unpivoted tree elimination against partially pivoted LU on both
