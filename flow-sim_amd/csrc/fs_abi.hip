@@ -55,6 +55,7 @@ struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 2),        \
   FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),   \
+  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, true),   \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
   FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),   \
@@ -92,6 +93,8 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1, 0, true), FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1, 0, true),
+                          FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1),
                           FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)};

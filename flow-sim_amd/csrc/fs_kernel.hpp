@@ -43,6 +43,9 @@
 #ifndef FS_SHARE_NODE
 #define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
 #endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
+#ifndef FS_WPE_RECT8
+#define FS_WPE_RECT8 2          // rectangular fast-path kernels with <= 8 cells per lane: the ragged (8,1) one needs 310 registers, capped at 256 it runs two waves per SIMD (+21 % at N = 300)
+#endif
 #ifndef FS_WPE_LEAN_POLY
 #define FS_WPE_LEAN_POLY 2      // the same for the polyline kernels (332 registers capped at 256: +79 % on the polyline ensemble)
 #endif
@@ -293,7 +296,7 @@ template <typename R, int M, int W> struct Smem {
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
 template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
-__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR ? FS_WPE_LEAN_POLY : FS_WPE_W1)))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8 ? FS_WPE_RECT8 : BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR ? FS_WPE_LEAN_POLY : FS_WPE_W1)))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;
