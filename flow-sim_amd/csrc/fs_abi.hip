@@ -13,7 +13,15 @@
 #include <string>
 #include <vector>
 
-#include "fs_kernel.hpp"
+#include "fs_entries.hpp"
+
+#ifndef FS_MINIMAL
+// the full library: the kernels are instantiated in the fs_part_*.hip translation units
+FS_LIST_RECT(FS_DECLARE, double, FS_F64) FS_LIST_RECT(FS_DECLARE, float, FS_F32)
+FS_LIST_TRAP(FS_DECLARE, double, FS_F64) FS_LIST_TRAP(FS_DECLARE, float, FS_F32)
+FS_LIST_TABLE(FS_DECLARE, double, FS_F64) FS_LIST_TABLE(FS_DECLARE, float, FS_F32)
+FS_LIST_IRREGULAR(FS_DECLARE)
+#endif
 
 namespace {
 
@@ -29,77 +37,43 @@ int fail(const std::string &m) { g_err = m; return -1; }
 
 struct Shape { int M, W; };
 
-typedef void (*LaunchFn)(const void *args, int B, hipStream_t st);
+typedef FsLaunchFn LaunchFn;
 typedef const void *KernelPtr;
-
-template <typename R, int SEC, int M, int W, bool RAGGED, int BCK>
-void launch_(const void *args, int B, hipStream_t st) {
-  const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK>), dim3(B), dim3(64 * W), 0, st, a);
-}
 
 // full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
 struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
-#define FS_BCK(kind) (2 + (kind))
-
-#define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK)                              \
-  { DT, SEC, M, W, FULL, (int)(BCK), &launch_<R, SEC, M, W, !(FULL), (int)(BCK)>,   \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> }
-#define FS_ENTRY(R, DT, SEC, M, W) FS_ENTRY_X(R, DT, SEC, M, W, 0, false)
-
-#define FS_ENTRIES(R, DT)                                                                         \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 2, 1),          \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 8, 1),          \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 1), FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 2),        \
-  FS_ENTRY(R, DT, FS_SEC_RECT_UNIFORM, 16, 4),                                                     \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),   \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, true),   \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, true),  \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),  \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),   \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 1, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 1, true), \
-  FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, true), FS_ENTRY_X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, true), \
-  FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1),          \
-  FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1),          \
-  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false), FS_ENTRY(R, DT, FS_SEC_TRAP_UNIFORM, 16, 4),  \
-  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)),                     \
-  FS_ENTRY_X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_RATING_POWER)),                     \
-  FS_ENTRY(R, DT, FS_SEC_TABLE, 1, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 2, 1),                        \
-  FS_ENTRY(R, DT, FS_SEC_TABLE, 4, 1), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 1),                        \
-  FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 2), FS_ENTRY(R, DT, FS_SEC_TABLE, 8, 4),                        \
-  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 1, 1, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 2, 1, 0, -1),      \
-  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 4, 1, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 1, 0, -1),      \
-  FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 2, 0, -1), FS_ENTRY_X(R, DT, FS_SEC_TABLE, 8, 4, 0, -1)
-// polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
-#define FS_ENTRIES_IRREGULAR                                                                      \
-  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 1, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),   \
-  FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 8, 4),   \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, -1), FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, -1), \
-  FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1), FS_ENTRY_X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)
+#define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
+  { DT, SEC, M, W, FULL, (int)(BCK), &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,             \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> },
+#define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
+#define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
 #if defined(FS_MINIMAL) && FS_MINIMAL == 2   // experiment builds: shapes for 512-node trapezoid reaches
-const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
-                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false),
-                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false),
+const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false)
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
-const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1, 0, true), FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1, 0, true),
-                          FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1), FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1),
-                          FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1), FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1),
-                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false),
+const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 4, 1, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1, 0, true) FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1, 0, true)
+                          FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_RECT_UNIFORM, 2, 1)
+                          FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1) FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1)
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)};
 #else
-const Entry kEntries[] = {FS_ENTRIES(double, FS_F64), FS_ENTRIES(float, FS_F32), FS_ENTRIES_IRREGULAR};
+const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
+                          FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
+                          FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
+                          FS_LIST_IRREGULAR(FS_TABLE_ROW)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the

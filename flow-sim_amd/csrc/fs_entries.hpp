@@ -1,0 +1,85 @@
+// Kernel instantiation lists (X-macros): one line per instantiation, X(R, DT, SEC, M, W, FULL, BCK).
+//   FULL == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
+//   BCK: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
+//        1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
+// fs_abi.hip builds its dispatch table from them; the fs_part_*.hip translation units instantiate them (compiled in
+// parallel by the Makefile: one translation unit with all ~130 kernels takes 2.5 minutes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fs_kernel.hpp"
+
+#define FS_BCK(kind) (2 + (kind))
+
+typedef void (*FsLaunchFn)(const void *args, int B, hipStream_t st);
+
+template <typename R, int SEC, int M, int W, bool RAGGED, int BCK>
+void fs_launch(const void *args, int B, hipStream_t st) {
+  const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK>), dim3(B), dim3(64 * W), 0, st, a);
+}
+
+#define FS_LIST_RECT(X, R, DT) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, 0) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 4, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 8, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 1, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, 1)
+
+#define FS_LIST_TRAP(X, R, DT) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1, 0, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1, 0, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1, 0, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 16, 4, 0, 0) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)) \
+  X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_RATING_POWER))
+
+#define FS_LIST_TABLE(X, R, DT) \
+  X(R, DT, FS_SEC_TABLE, 1, 1, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 2, 1, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 4, 1, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 8, 1, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 8, 2, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 8, 4, 0, 0) \
+  X(R, DT, FS_SEC_TABLE, 1, 1, 0, -1) \
+  X(R, DT, FS_SEC_TABLE, 2, 1, 0, -1) \
+  X(R, DT, FS_SEC_TABLE, 4, 1, 0, -1) \
+  X(R, DT, FS_SEC_TABLE, 8, 1, 0, -1) \
+  X(R, DT, FS_SEC_TABLE, 8, 2, 0, -1) \
+  X(R, DT, FS_SEC_TABLE, 8, 4, 0, -1)
+
+// polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
+#define FS_LIST_IRREGULAR(X) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, -1) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, -1) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)
+
+// explicit instantiation (fs_part_*.hip) / extern declaration (fs_abi.hip) of one entry
+#define FS_INSTANTIATE(R, DT, SEC, M, W, FULL, BCK)                                                            \
+  template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>(const fs::KernelArgs<R>); \
+  template void fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>(const void *, int, hipStream_t);
+#define FS_DECLARE(R, DT, SEC, M, W, FULL, BCK)                                                                       \
+  extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>(const fs::KernelArgs<R>); \
+  extern template void fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>(const void *, int, hipStream_t);

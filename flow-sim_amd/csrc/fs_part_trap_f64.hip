@@ -1,0 +1,4 @@
+// kernel instantiations of libflowsim_hip.so, part "trap_f64" (see fs_entries.hpp)
+#include "fs_entries.hpp"
+
+FS_LIST_TRAP(FS_INSTANTIATE, double, FS_F64)
