@@ -138,6 +138,8 @@ def main():
                          "geometry with a Manning-n Monte-Carlo ensemble (use with --reaches 32768; nodes fixed at 121); irr: "
                          "polyline (IrregularSection) channel with a levee, Manning-n ensemble (use with --reaches 8192; "
                          "129 nodes)")
+    ap.add_argument("--spatial-step", type=float, default=None,
+                    help="c4 only: override the case's spatial step (m); the node count follows (default 1000 m: 121 nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true",
@@ -185,7 +187,8 @@ def main():
         from cases.gerd_roseires.model import build as build_gerd
         from flowsim_amd.ensemble import gvf_profiles
         from flowsim_amd.hydromodel.preissmann import boundary_to_spec
-        solver, _ = build_gerd(inflow_hyd_func=None, sim_duration=(levels - 1) * 3600)
+        extra = {} if args.spatial_step is None else {"spatial_step": args.spatial_step}
+        solver, _ = build_gerd(inflow_hyd_func=None, sim_duration=(levels - 1) * 3600, **extra)
         ch = solver.channel
         N = solver.number_of_nodes
         rng = np.random.default_rng(20260215)
@@ -199,8 +202,8 @@ def main():
         ic = gvf_profiles(ch, n_members)
         batch.set_state(ic[:, :, 0], ic[:, :, 1])
         Qb = None
-        desc = ("C4: cases/gerd_roseires (121 nodes, compound sections + curvature, Roseires gate curve), %d-member "
-                "Manning-n ensemble per GPU, theta 0.6, dt 3600 s, tol 1e-6" % B)
+        desc = ("C4: cases/gerd_roseires (%d nodes, compound sections + curvature, Roseires gate curve), %d-member "
+                "Manning-n ensemble per GPU, theta 0.6, dt 3600 s, tol 1e-6" % (N, B))
     elif args.workload == "irr":
         # polyline sections (8 -> 15 stations after interpolation, berm on the right bank),
         # composite roughness over three strips, one channel shared by a Manning-n ensemble

@@ -295,8 +295,21 @@ template <typename R, int M, int W> struct Smem {
 // residual is kept in qc.
 template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
 
+// Minimum number of waves per SIMD a kernel is compiled for: caps its registers at 512 / n.  One wave per SIMD cannot
+// hide the latency of the in-wave tree, a second one is worth 20-80 % wherever the kernel fits 256 registers or nearly
+// does; forcing it on the larger kernels sends them to scratch (measured 0.25-0.8x).
+template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() {
+  if (W > 1) return 1;          // multi-wave table kernels with 2 cells per lane at two waves per SIMD: no better than the 4- and 8-cell ones
+  if (sizeof(R) == 4) return FS_WPE_W1_F32;
+  if (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8) return FS_WPE_RECT8;
+  if (BCK >= 2 && M <= 2) return FS_WPE_PINNED_SHORT;
+  if (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE) return FS_WPE_LEAN_SHORT;
+  if (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR) return FS_WPE_LEAN_POLY;
+  return FS_WPE_W1;
+}
+
 template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
-__global__ __launch_bounds__(64 * W, (W == 1 ? (sizeof(R) == 4 ? FS_WPE_W1_F32 : (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8 ? FS_WPE_RECT8 : BCK >= 2 && M <= 2 ? FS_WPE_PINNED_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE ? FS_WPE_LEAN_SHORT : (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR ? FS_WPE_LEAN_POLY : FS_WPE_W1)))) : 1)) void preissmann_step_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   __shared__ Smem<R, M, W> sm;
