@@ -25,6 +25,10 @@ constexpr double kG = 9.80665;  // scipy.constants.g (hydraulics.py:2)
 #ifndef FS_RCP_NR
 #define FS_RCP_NR 1
 #endif
+// fused multiply-add in the working precision (__builtin_fma on floats is the double one: two conversions in, one out)
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 __device__ __forceinline__ double frcp(double x) {
   // v_rcp_f64 seed (measured on gfx950: 2^-24.4 relative, tools/micro/rcp_prec.hip) + Newton steps:
   // one step leaves <= 2.3e-15 relative (~10 ulp), two steps are correctly rounded.  The kernel's
@@ -160,7 +164,7 @@ template <typename R>
 __device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q) {
   NodeTerms<R> t;
   const R A = b * h;
-  const R P = __builtin_fma(R(2), h, b);
+  const R P = fma_(R(2), h, b);
   const R r = frcp(P * h);
   const R rP = r * h, rh = r * P;
   const R Rh = A * rP;                   // hydraulic radius
@@ -173,7 +177,7 @@ __device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q
   t.T = b;
   t.Se = Q * aQ * iK2;                                             // hydraulics.py:57
   t.eQ = R(2) * aQ * iK2;                                          // hydraulics.py:92
-  t.eA = R(-2) * t.Se * __builtin_fma(R(2.0 / 3.0) * b, rP, R(1)) * rh;  // hydraulics.py:75 times T
+  t.eA = R(-2) * t.Se * fma_(R(2.0 / 3.0) * b, rP, R(1)) * rh;  // hydraulics.py:75 times T
   t.v = Q * rA;
   return t;
 }
@@ -185,9 +189,9 @@ template <typename R>
 __device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R h, R Q) {
   NodeTerms<R> t;
   const R mh = m * h;
-  const R T = __builtin_fma(R(2), mh, b);
+  const R T = fma_(R(2), mh, b);
   const R A = (b + mh) * h;
-  const R P = __builtin_fma(sm2, h, b);          // sm2 = 2 sqrt(1 + m^2)
+  const R P = fma_(sm2, h, b);          // sm2 = 2 sqrt(1 + m^2)
   const R AP = A * P;
   const R r3 = frcp(AP * T);
   const R rA = r3 * (P * T), rP = r3 * (A * T), rT = r3 * AP;
@@ -627,7 +631,7 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<
       const R rn = frcp(n);
       // K = A R^(2/3) / n ; dK/dA * T = K (1 + (2/3) b/P) / h        (rectangle)
       const R hd = h + bed - zsec;                                      // df_dh uses hw = h + bed_level
-      const R P = __builtin_fma(R(2), h, b);
+      const R P = fma_(R(2), h, b);
       if (hd == h) {
         // the usual case (boundary bed level == section bed): one reciprocal serves both evaluations,
         // 1/h = P/(P h) and b/P = b h/(P h)
@@ -635,16 +639,16 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<
         const R Rh = b * h * h * q;
         const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
         r.res = Q - srt * K;
-        r.dh = R(0) - srt * K * __builtin_fma(R(2.0 / 3.0) * b * h, q, R(1)) * (P * q);
+        r.dh = R(0) - srt * K * fma_(R(2.0 / 3.0) * b * h, q, R(1)) * (P * q);
       } else {
         const R Rh = b * h * frcp(P);
         const R K = b * h * Rh * rcbrt_pos(Rh) * rn;
-        const R Pd = __builtin_fma(R(2), hd, b);
+        const R Pd = fma_(R(2), hd, b);
         const R rPd = frcp(Pd);
         const R Rd = b * hd * rPd;
         const R Kd = b * hd * Rd * rcbrt_pos(Rd) * rn;
         r.res = Q - srt * K;
-        r.dh = R(0) - srt * Kd * __builtin_fma(R(2.0 / 3.0) * b, rPd, R(1)) * frcp(hd);
+        r.dh = R(0) - srt * Kd * fma_(R(2.0 / 3.0) * b, rPd, R(1)) * frcp(hd);
       }
       r.dq = R(1);
     } break;
