@@ -55,6 +55,9 @@
 #ifndef FS_WPE_PINNED_SHORT
 #define FS_WPE_PINNED_SHORT 2   // the same for kernels with the boundary kinds fixed at compile time
 #endif
+#ifndef FS_WPE_W1_F32_UNIFORM
+#define FS_WPE_W1_F32_UNIFORM 3   // fp32, uniform geometry, <= 8 cells per lane: 207 registers capped at 168, three waves per SIMD (C5 +14 %; four: -24 %)
+#endif
 #ifndef FS_WPE_W1_F32
 #define FS_WPE_W1_F32 2    // the same for fp32: two waves per SIMD fit (<= 256 registers) and hide the tree's latency (C5 fp32 +18 %)
 #endif
@@ -300,7 +303,7 @@ template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   //
 // does; forcing it on the larger kernels sends them to scratch (measured 0.25-0.8x).
 template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() {
   if (W > 1) return 1;          // multi-wave table kernels with 2 cells per lane at two waves per SIMD: no better than the 4- and 8-cell ones
-  if (sizeof(R) == 4) return FS_WPE_W1_F32;
+  if (sizeof(R) == 4) return (M <= 8 && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM)) ? FS_WPE_W1_F32_UNIFORM : FS_WPE_W1_F32;
   if (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8) return FS_WPE_RECT8;
   if (BCK >= 2 && M <= 2) return FS_WPE_PINNED_SHORT;
   if (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE) return FS_WPE_LEAN_SHORT;
