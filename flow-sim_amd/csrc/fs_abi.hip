@@ -250,10 +250,10 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc((void **)&b->status, B * 4)) != hipSuccess) return bad("hipMalloc(status)", e);
   if ((e = hipMalloc(&b->Yprev, B * b->esz)) != hipSuccess) return bad("hipMalloc(Yprev)", e);
   if ((e = hipMalloc(&b->stage_hist, L * B * b->esz)) != hipSuccess) return bad("hipMalloc(stage_hist)", e);
-  hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream);
+  (void)hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream);
   if (desc->flags & FS_FLAG_TRACE) {
     if ((e = hipMalloc(&b->trace, L * FS_TRACE_CAP * B * b->esz)) != hipSuccess) return bad("hipMalloc(trace)", e);
-    hipMemsetAsync(b->trace, 0, L * FS_TRACE_CAP * B * b->esz, b->stream);
+    (void)hipMemsetAsync(b->trace, 0, L * FS_TRACE_CAP * B * b->esz, b->stream);
   }
   if (desc->flags & FS_FLAG_HISTORY) {
     if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
@@ -263,24 +263,24 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc((void **)&b->dbg, B * 16 * 12 * 8)) != hipSuccess) return bad("hipMalloc(dbg)", e);
   hipMemsetAsync(b->dbg, 0, B * 16 * 12 * 8, b->stream);
 #endif
-  hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
-  hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);
-  hipMemsetAsync(b->status, 0, B * 4, b->stream);
-  hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream);
-  hipStreamSynchronize(b->stream);
+  (void)hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
+  (void)hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);
+  (void)hipMemsetAsync(b->status, 0, B * 4, b->stream);
+  (void)hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream);
+  (void)hipStreamSynchronize(b->stream);
   return b;
 }
 
 void fs_batch_destroy(fs_batch *b) {
   if (!b) return;
-  if (b->stream) hipStreamSynchronize(b->stream);
+  if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n};
-  for (void *p : bufs) if (p) hipFree(p);
-  if (b->ev0) hipEventDestroy(b->ev0);
-  if (b->ev1) hipEventDestroy(b->ev1);
-  if (b->stream) hipStreamDestroy(b->stream);
+  for (void *p : bufs) if (p) (void)hipFree(p);
+  if (b->ev0) (void)hipEventDestroy(b->ev0);
+  if (b->ev1) (void)hipEventDestroy(b->ev1);
+  if (b->stream) (void)hipStreamDestroy(b->stream);
   delete b;
 }
 
@@ -314,7 +314,7 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
   } else if (b->n_override) {
-    hipFree(b->n_override); b->n_override = nullptr;
+    (void)hipFree(b->n_override); b->n_override = nullptr;
   }
   b->have_geo = true;
   return 0;
@@ -349,8 +349,8 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
   }
   if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * N)) return -1;
-  if (b->poly_x) { hipFree(b->poly_x); b->poly_x = nullptr; }
-  if (b->poly_z) { hipFree(b->poly_z); b->poly_z = nullptr; }
+  if (b->poly_x) { (void)hipFree(b->poly_x); b->poly_x = nullptr; }
+  if (b->poly_z) { (void)hipFree(b->poly_z); b->poly_z = nullptr; }
   if (upload(b, &b->poly_x, xt.data(), P * N) || upload(b, &b->poly_z, zt.data(), P * N) ||
       upload(b, &b->poly_lim, lim.data(), 2 * N)) return -1;
   if (!b->poly_n) HIP_TRY(hipMalloc((void **)&b->poly_n, N * 4));
@@ -358,7 +358,7 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
   } else if (b->n_override) {
-    hipFree(b->n_override); b->n_override = nullptr;
+    (void)hipFree(b->n_override); b->n_override = nullptr;
   }
   b->have_geo = true;
   return 0;
@@ -386,8 +386,8 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
     return fail("Insufficient arguments for boundary condition.");                                // boundary.py:87
   if (fs::bc_is_storage(kind) && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
   const size_t B = b->d.n_reaches;
-  if (b->bc_params[side]) { hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
-  if (b->bc_target[side]) { hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
+  if (b->bc_params[side]) { (void)hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
+  if (b->bc_target[side]) { (void)hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
   if (n_params > 0 && upload(b, &b->bc_params[side], params, per_reach ? n_params * B : (size_t)n_params)) return -1;
   if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
   b->bc_kind[side] = kind; b->bc_stride[side] = per_reach ? 1 : 0;
@@ -438,7 +438,7 @@ int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  hipFree(dh); hipFree(dQ);
+  (void)hipFree(dh); (void)hipFree(dQ);
   b->level = 0;
   b->have_state = true;
   return 0;
@@ -557,7 +557,7 @@ int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double
     if (host[f] && hipMalloc(&dev[f], (f == 7 ? BN : BN * n) * b->esz) != hipSuccess) rc = fail("fs_batch_derive: hipMalloc failed");
   if (!rc) {
     const dim3 grid((unsigned)((BN + 255) / 256));
-    hipEventRecord(b->ev0, b->stream);      // fs_batch_last_step_ms() then reports this kernel
+    (void)hipEventRecord(b->ev0, b->stream);      // fs_batch_last_step_ms() then reports this kernel
     if (b->d.dtype == FS_F64) {
       fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
                                (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
@@ -573,13 +573,13 @@ int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double
                               (float *)dev[5], (float *)dev[6], (float *)dev[7]};
       hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);
     }
-    hipEventRecord(b->ev1, b->stream);
+    (void)hipEventRecord(b->ev1, b->stream);
     b->timed = true; b->launches = 1;
     if (hipGetLastError() != hipSuccess) rc = fail("fs_batch_derive: launch failed");
     for (int f = 0; f < 8 && !rc; ++f)
       if (host[f]) rc = download(b, host[f], dev[f], 0, f == 7 ? BN : BN * n);
   }
-  for (void *p : dev) if (p) hipFree(p);
+  for (void *p : dev) if (p) (void)hipFree(p);
   return rc;
 }
 

@@ -113,6 +113,14 @@ template <typename R> struct KernelArgs {
 
 template <typename R, int SEC> struct Geometry;
 
+// the descriptor with its kind pinned to what the instantiation was compiled for (BCK >= 2)
+template <int BCK, int SIDE, typename R>
+__device__ __forceinline__ BCDesc<R> pinned(const BCDesc<R> &bc) {
+  BCDesc<R> d = bc;
+  if (BCK >= 2) d.kind = SIDE == 0 ? (int)FS_BC_FLOW_HYDROGRAPH : BCK - 2;
+  return d;
+}
+
 template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   static constexpr bool kConstT = true;      // dA/dh = b everywhere: no per-node top width to keep
   R b, rb, n, z_us, z_ds, inv_nm1, dz;
@@ -147,14 +155,6 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
     return bc_eval<BCK != 0>(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
-
-// the descriptor with its kind pinned to what the instantiation was compiled for (BCK >= 2)
-template <int BCK, int SIDE, typename R>
-__device__ __forceinline__ BCDesc<R> pinned(const BCDesc<R> &bc) {
-  BCDesc<R> d = bc;
-  if (BCK >= 2) d.kind = SIDE == 0 ? (int)FS_BC_FLOW_HYDROGRAPH : BCK - 2;
-  return d;
-}
 
 template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   static constexpr bool kConstT = false;

@@ -27,6 +27,10 @@
 #define FS_POLY_ATTR __noinline__
 #endif
 
+#ifndef FS_POLY_PREFETCH
+#define FS_POLY_PREFETCH 1
+#endif
+
 namespace fs {
 
 // vertex j of a node lives at x[j * stride], z[j * stride] (vertex-major [P][N] tables: the lanes
@@ -89,8 +93,17 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
   R A0 = 0, P0 = 0, T0 = 0, A1 = 0, P1 = 0, A2 = 0, P2 = 0, Td = 0;
   R Al = 0, Pl = 0, Am = 0, Pm = 0, Ar = 0, Pr = 0;
   R x0 = xa, z0 = Z(j0);
+#if FS_POLY_PREFETCH
+  // the next vertex is requested one edge ahead: an edge is ~300 instructions, a vertex load an L2 round trip
+  R xn = X(min(j0 + 1, j1)), zn = Z(min(j0 + 1, j1));
+#endif
   for (int j = j0; j < j1; ++j) {
+#if FS_POLY_PREFETCH
+    const R x1 = xn, z1 = zn;
+    xn = X(min(j + 2, j1)); zn = Z(min(j + 2, j1));
+#else
     const R x1 = X(j + 1), z1 = Z(j + 1);
+#endif
     const R dx = x1 - x0, dz = z1 - z0;
     // full length: needed as soon as both ends are wet at the highest of the three stages
     const R len = (hw + dh > z0 && hw + dh > z1) ? fsqrt_len(dx * dx + dz * dz) : R(0);
