@@ -69,7 +69,8 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
                           FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1) FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
-                          FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)};
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
+                          FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)};
 #else
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)

@@ -43,6 +43,9 @@
 #ifndef FS_SHARE_NODE
 #define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
 #endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
+#ifndef FS_WPE_TRAP4
+#define FS_WPE_TRAP4 2          // trapezoid kernels with 4 cells per lane: 348 registers capped at 256 (+29 % at N = 200; the table kernel of that shape, 406 registers, loses 20 % when capped)
+#endif
 #ifndef FS_WPE_RECT8
 #define FS_WPE_RECT8 2          // rectangular fast-path kernels with <= 8 cells per lane: the ragged (8,1) one needs 310 registers, capped at 256 it runs two waves per SIMD (+21 % at N = 300)
 #endif
@@ -307,6 +310,7 @@ template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() 
   if (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8) return FS_WPE_RECT8;
   if (BCK >= 2 && M <= 2) return FS_WPE_PINNED_SHORT;
   if (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE) return FS_WPE_LEAN_SHORT;
+  if (BCK == 0 && M == 4 && SEC == FS_SEC_TRAP_UNIFORM) return FS_WPE_TRAP4;
   if (BCK == 0 && M <= 2 && SEC == FS_SEC_IRREGULAR) return FS_WPE_LEAN_POLY;
   return FS_WPE_W1;
 }
