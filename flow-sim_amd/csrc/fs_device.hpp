@@ -377,7 +377,7 @@ __device__ __forceinline__ R rating_blend(R z, R s0, R buf, R l0, R l1, R l2, R 
   R al;
   if (z >= s0 + buf) al = R(1);
   else if (z <= s0) al = R(0);
-  else { const R s = (z - s0) / buf; al = R(3) * s * s - R(2) * s * s * s; }
+  else { const R s = (z - s0) * frcp(buf); al = R(3) * s * s - R(2) * s * s * s; }
   const R lo = l0 + l1 * z + l2 * z * z;
   const R hi = h0 + h1 * z + h2 * z * z;
   return (R(1) - al) * lo + al * hi;
@@ -584,7 +584,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
       const R qp = rating_blend(z + dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
       const R qm = rating_blend(z - dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
       r.res = Q - q0;
-      r.dh = R(0) - (qp - qm) / (R(2) * dY);                            // roseires_rating_curve.py:202-208
+      r.dh = R(0) - (qp - qm) * frcp(R(2) * dY);                            // roseires_rating_curve.py:202-208
       r.dq = R(1);
     } break;
     case FS_BC_STORAGE: {
@@ -671,7 +671,7 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<
       const R qp = rating_blend(z + dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
       const R qm = rating_blend(z - dY, p(0), p(1), p(2), p(3), p(4), p(5), p(6), p(7));
       r.res = Q - q0;
-      r.dh = R(0) - (qp - qm) / (R(2) * dY);
+      r.dh = R(0) - (qp - qm) * frcp(R(2) * dY);
       r.dq = R(1);
     } break;
     case FS_BC_STORAGE: {
