@@ -211,7 +211,10 @@ __device__ FS_POLY_ATTR BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0
   const R sg = S0 < R(0) ? R(-1) : R(1);
   const R rt = sqrt_(fabs_(S0));
   const PolyEval<R> gr = poly_eval(nd, poly_whole(nd), nd.zmin + h);
-  const PolyEval<R> gd = poly_eval(nd, poly_whole(nd), h + bed);
+  // boundary.py:165-181 takes the residual at the section's own datum and the derivative at the boundary's bed level; they
+  // are usually the same stage, and a section walk here costs the reach's only wave as much as a node of the fold
+  PolyEval<R> gd = gr;
+  if (h + bed != nd.zmin + h) gd = poly_eval(nd, poly_whole(nd), h + bed);
   BCRow<R> r;
   r.res = Q - sg * gr.K * rt;
   r.dh = R(0) - sg * gd.dKdA * rt * gd.dAdh;
