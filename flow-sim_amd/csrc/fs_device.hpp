@@ -560,7 +560,9 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
       const R sg = S0 < R(0) ? R(-1) : R(1);
       const R rt = sqrt_(fabs_(S0));
       const GeneralProps<R> gr = general_props_call(sec, h);                 // residual: hw = z_min + h
-      const GeneralProps<R> gd = general_props_call(sec, h + bed - sec.z);   // df_dh: hw = h + bed_level
+      const R hd = h + bed - sec.z;                                           // df_dh: hw = h + bed_level
+      GeneralProps<R> gd = gr;                                                // usually the same depth: one evaluation
+      if (hd != h) gd = general_props_call(sec, hd);
       r.res = Q - sg * gr.K * rt;                                       // hydraulics.py:4-13
       r.dh = R(0) - sg * gd.dKdA * rt * gd.T;                           // hydraulics.py:206-215
       r.dq = R(1);
