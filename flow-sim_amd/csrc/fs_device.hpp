@@ -571,7 +571,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
       const R x = p(3) + h + p(2);
       const R q = p(0) * pow_(x, p(1));                                 // rating_curve.py:59
       r.res = Q - q;
-      r.dh = R(0) - p(1) * q / x;                                       // a b x^(b-1) (:143) from the one pow()
+      r.dh = R(0) - p(1) * q * frcp(x);                                 // a b x^(b-1) (:143) from the one pow()
       r.dq = R(1);
     } break;
     case FS_BC_RATING_POLY: {
