@@ -40,6 +40,12 @@
 #ifndef FS_WPE_W1
 #define FS_WPE_W1 1        // min waves/SIMD the one-wave-per-reach kernels are compiled for (2..4 measured: scratch spills, 0.25-0.8x)
 #endif
+#ifndef FS_SAVE_TERMS_MAXM_F64
+#define FS_SAVE_TERMS_MAXM_F64 2   // 4 and 8 cells per lane measured: trapezoid -13 % / -3 %, table +1 % (the LDS traffic of every fold outweighs one pass per level)
+#endif
+#ifndef FS_SAVE_TERMS
+#define FS_SAVE_TERMS 1
+#endif
 #ifndef FS_SHARE_NODE
 #define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
 #endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
@@ -283,7 +289,11 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
 // registers (20 per lane) so that the LDS slots of levels 1..5 (31 per wave) fit next to kc.
 template <int W> struct TreeCfg { static constexpr bool kL0Regs = (W >= 8); static constexpr int kSlots = kL0Regs ? 32 : 64; };
 
-template <typename R, int M, int W> struct Smem {
+// (A, Se, Q/A) of the nodes as the last fold saw them (kSaveTerms); an empty base otherwise
+template <typename R, int M, int T, bool SAVE> struct SavedTerms { R nt[3][M + 1][T]; };
+template <typename R, int M, int T> struct SavedTerms<R, M, T, false> {};
+
+template <typename R, int M, int W, bool SAVE> struct Smem : SavedTerms<R, M, 64 * W, SAVE> {
   static constexpr int T = 64 * W;
   R kc[4][M][T];           // per-cell level-k constants, lane-minor (conflict-free ds_read_b64)
   R tree[W][10][TreeCfg<W>::kSlots];   // per-wave spill slots of the in-wave tree
@@ -319,7 +329,11 @@ template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
 __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
-  __shared__ Smem<R, M, W> sm;
+  // Short general-section kernels keep (A, Se, Q/A) of every node of the current fold in LDS: if the iterate is accepted they
+  // are the node terms of level k, and the level constants of level k+1 come from them instead of from another pass over the
+  // sections (1 of 6 section passes of the polyline ensemble, 1 of 11 of C4)
+  constexpr bool kSaveTerms = FS_SAVE_TERMS && !Geometry<R, SEC>::kConstT && (M <= 2 || (sizeof(R) == 8 && M <= FS_SAVE_TERMS_MAXM_F64));
+  __shared__ Smem<R, M, W, kSaveTerms> sm;
 
   const int reach = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -375,6 +389,24 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #if FS_LEVEL_FENCE
       if ((c % FS_LEVEL_FENCE) == FS_LEVEL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
 #endif
+    }
+  };
+  auto save_terms = [&](int j, const NodeTerms<R> &nt) {
+    if constexpr (kSaveTerms) { sm.nt[0][j][t] = nt.A; sm.nt[1][j][t] = nt.Se; sm.nt[2][j][t] = nt.v; }
+  };
+  auto level_constants_from_saved = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+    if constexpr (kSaveTerms) {
+      R A0 = sm.nt[0][0][t], Se0 = sm.nt[1][0][t], v0 = sm.nt[2][0][t];
+#pragma unroll
+      for (int c = 0; c < M; ++c) {
+        const R A1 = sm.nt[0][c + 1][t], Se1 = sm.nt[1][c + 1][t], v1 = sm.nt[2][c + 1][t];
+        const R sumA = A0 + A1;
+        sm.kc[0][c][t] = -sumA * r2dt + cqk * (QQ[c + 1] - QQ[c]);
+        sm.kc[1][c][t] = -(QQ[c + 1] + QQ[c]) * r2dt + cqk * (QQ[c + 1] * v1 - QQ[c] * v0);
+        sm.kc[2][c][t] = hthk * sumA;
+        sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (Se0 + Se1);
+        A0 = A1; Se0 = Se1; v0 = v1;
+      }
     }
   };
 
@@ -461,12 +493,14 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
         NodeTerms<R> Rlast;
         if (kShareNode) Rlast = last_node_terms(L, h[M], Q[M]);
+        save_terms(0, L);
         if (!Geo::kConstT) Tn[0] = L.T;
         R kap = R(1);                      // the M-like row keeps the direction of cell 0's: pm = kap * (pf0, pf1)
 #pragma unroll
         for (int c = 0; c < M; ++c) {
           const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
           const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+          save_terms(c + 1, Rn);
           if (!Geo::kConstT) Tn[c + 1] = Rn.T;
           Seg<R> cell;
           {
@@ -794,7 +828,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           for (int j = kJD0; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
         }
         FS_T(9);
-        write_level_constants(h, Q);                                  // level constants of the next level
+        if (kSaveTerms) level_constants_from_saved(h, Q);             // level constants of the next level
+        else write_level_constants(h, Q);
         FS_T(10);
       }
 
