@@ -58,7 +58,8 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
-const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
+const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, true)
@@ -98,7 +99,7 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, std::strin
     if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2 || general_only)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
-    auto rank = [](const Entry &x) { return x.full + (x.bck >= 1 ? 2 : x.bck == 0 ? 1 : 0); };
+    auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
         (e.M == best->M && e.W == best->W && spec > bspec))

@@ -621,7 +621,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
 // state around it).  Only the kinds that need no pow() are inlined (bc_is_light): the power rating
 // curve drags ~50 SGPR constants and ~300 instructions of pow() into the hot loop otherwise.
 // zsec = bed level of the boundary node's section.
-__host__ __device__ inline bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind != FS_BC_STORAGE_CURVE; }
+__host__ __device__ constexpr bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind != FS_BC_STORAGE_CURVE; }
 
 // lp: this reach's parameters in LDS (typed pointer: ds_read, not a flat load through a generic one)
 template <typename R> using LdsParams = const __attribute__((address_space(3))) R *;

@@ -39,7 +39,13 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 1, 1) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 1, 1) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, 1) \
-  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, 1)
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, 1) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
 
 #define FS_LIST_TRAP(X, R, DT) \
   X(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1, 0, 0) \

@@ -25,9 +25,9 @@
 // BCK (boundary-kind class the kernel is compiled for): -1 = any kinds, 0 = any but FS_BC_STORAGE_CURVE (the row
 // evaluation switches at run time),
 // 1 = RECT_UNIFORM with bc_is_light() kinds on both ends (closed-form rows, parameters in LDS), 2 + k = flow
-// hydrograph upstream and kind k downstream, known at compile time: the switch over the nine kinds folds
-// away and with it a third of the registers of the general-section kernels (C5 +10 % fp32 / +25 % fp64,
-// C4 +20 %).  fs_abi.hip picks the most specific instantiation that matches the batch.
+// hydrograph upstream and kind k downstream, known at compile time: the switch over the kinds folds away (rows the
+// reach never evaluates still cost registers and shape the code around them: flagship +1.5 %, C5 +2-3.5 %).
+// fs_abi.hip picks the most specific instantiation that matches the batch.
 #pragma once
 #include <type_traits>
 #include "fs_device.hpp"
@@ -159,8 +159,10 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
-    if (BCK == 1)   // bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only)
-      return bc_eval_rect(bc, (LdsParams<R>)bc.params, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
+    // closed-form rows, bc.params points at the LDS copy made in the kernel prologue (fixed-size kinds only); with the kinds
+    // fixed at compile time the rows this reach never evaluates are not compiled in (the flagship kernel: +1.5 %)
+    if (BCK == 1 || (BCK >= 2 && bc_is_light(BCK - 2)))
+      return bc_eval_rect(pinned<BCK, SIDE>(bc), (LdsParams<R>)bc.params, level, b, n, node == 0 ? z_us : z_ds, h, Q, Qold, dt, Yprev, Ynew, flag);
     return bc_eval<BCK != 0>(pinned<BCK, SIDE>(bc), reach, B, level, section(node), h, Q, Qold, dt, Yprev, Ynew, flag);
   }
 };
@@ -317,7 +319,7 @@ template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   //
 template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() {
   if (W > 1) return 1;          // multi-wave table kernels with 2 cells per lane at two waves per SIMD: no better than the 4- and 8-cell ones
   if (sizeof(R) == 4) return (M <= 8 && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM)) ? FS_WPE_W1_F32_UNIFORM : FS_WPE_W1_F32;
-  if (SEC == FS_SEC_RECT_UNIFORM && BCK == 1 && M <= 8) return FS_WPE_RECT8;
+  if (SEC == FS_SEC_RECT_UNIFORM && BCK >= 1 && M <= 8) return FS_WPE_RECT8;
   if (BCK >= 2 && M <= 2) return FS_WPE_PINNED_SHORT;
   if (BCK == 0 && M <= 2 && SEC == FS_SEC_TABLE) return FS_WPE_LEAN_SHORT;
   if (BCK == 0 && M == 4 && SEC == FS_SEC_TRAP_UNIFORM) return FS_WPE_TRAP4;

@@ -523,20 +523,23 @@ def test_flow_regime_grid_against_the_c_oracle():
                 assert np.array_equal(its, ref["iters"]), (S0, dx, q)
 
 
-@pytest.mark.parametrize("case", ["trap_512", "trap_500"])
+@pytest.mark.parametrize("case", ["trap_512", "trap_500", "rect_512"])
 def test_kernels_compiled_for_a_boundary_pair_match_the_general_ones(case, monkeypatch):
     """Instantiations with the downstream kind fixed at compile time (BCK >= 2, fs_kernel.hpp) against the
     general kernels of the same shape (FS_KERNEL_GENERAL=1): same rows, same source - equal iteration counts,
     hydrographs equal to a few ulp (the compiler contracts a row inlined next to one kind differently from
     the same row next to nine), and fewer registers (which is the point of them)."""
     from fixture_batch import batch_from_problems
-    if case.startswith("trap"):
+    if case.startswith("rect"):
+        _, _, probs = problems_of(os.path.join(GOLDEN, "synthetic_rect_512.npz"))
+        mode = "rect_uniform"
+    elif case.startswith("trap"):
         probs = _singular_pivot_problems(int(case[5:]), 5, 1e-6)[:4]
         mode = "trap_uniform"
     else:
         _, _, probs = problems_of(os.path.join(GOLDEN, case + ".npz"))
         probs, mode = probs[:1], "table"
-    monkeypatch.setenv("FS_KERNEL_SHAPE", "8,1" if mode == "trap_uniform" else "2,1")
+    monkeypatch.setenv("FS_KERNEL_SHAPE", "2,1" if mode == "table" else "8,1")
     n = min(probs[0].nt - 1, 6)
     out = []
     for general in ("1", "0"):
