@@ -540,7 +540,7 @@ template <typename R> __device__ __forceinline__ EntryProps<R> entry_props(const
   return e;
 }
 
-__host__ __device__ inline bool bc_is_storage(int kind) { return kind == FS_BC_STORAGE || kind == FS_BC_STORAGE_CURVE; }
+__host__ __device__ constexpr bool bc_is_storage(int kind) { return kind == FS_BC_STORAGE || kind == FS_BC_STORAGE_CURVE; }
 
 // sec: section of the boundary node; Qold: flow[k-1] at that node; Yprev: storage stage of level
 // k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).

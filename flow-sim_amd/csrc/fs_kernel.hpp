@@ -439,7 +439,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   if (usd.kind <= FS_BC_STORAGE) { usd.params = &sm.bcp[0][0]; usd.stride = 0; }
   if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
 
-  R Yprev = (bc_is_storage(a.ds.kind) && t == tD) ? a.Yprev[reach] : R(0);
+  // a compile-time constant in the kernels compiled for a boundary pair
+  const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(a.ds.kind);
+  R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
   int parity = 0;
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
@@ -823,7 +825,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
               a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
             }
           Yprev = Ynew;
-          if (bc_is_storage(a.ds.kind)) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
+          if (ds_storage) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
         }
         if (t == tD) {
 #pragma unroll
@@ -849,7 +851,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     if ((j < M || node == N - 1) && node < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
   }
   if (t == 0) a.status[reach] = status;
-  if (bc_is_storage(a.ds.kind) && t == tD) a.Yprev[reach] = Yprev;
+  if (ds_storage && t == tD) a.Yprev[reach] = Yprev;
 #ifdef FS_STAMP
   if (a.dbg && lane == 0)
     for (int i = 0; i < 12; ++i) a.dbg[((size_t)reach * 16 + wave) * 12 + i] = stamp_[i];
