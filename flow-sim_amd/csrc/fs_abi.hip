@@ -21,6 +21,7 @@ FS_LIST_RECT(FS_DECLARE, double, FS_F64) FS_LIST_RECT(FS_DECLARE, float, FS_F32)
 FS_LIST_TRAP(FS_DECLARE, double, FS_F64) FS_LIST_TRAP(FS_DECLARE, float, FS_F32)
 FS_LIST_TABLE(FS_DECLARE, double, FS_F64) FS_LIST_TABLE(FS_DECLARE, float, FS_F32)
 FS_LIST_IRREGULAR(FS_DECLARE)
+FS_LIST_NODIAG(FS_DECLARE_NODIAG)
 #endif
 
 namespace {
@@ -43,10 +44,13 @@ typedef const void *KernelPtr;
 // full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
-struct Entry { int dtype, sec, M, W, full, bck; LaunchFn fn; KernelPtr kp; };
+struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; };   // diag == 0: no history / trace stores
 #define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
-  { DT, SEC, M, W, FULL, (int)(BCK), &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,             \
+  { DT, SEC, M, W, FULL, (int)(BCK), 1, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,          \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> },
+#define FS_TABLE_ROW_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                       \
+  { DT, SEC, M, W, FULL, (int)(BCK), 0, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>,    \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false> },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -58,7 +62,8 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
-const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
+const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
+                          FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1, true)
@@ -76,12 +81,12 @@ const Entry kEntries[] = {FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4,
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
-                          FS_LIST_IRREGULAR(FS_TABLE_ROW)};
+                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
 // choice for experiments and tests.
-const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, std::string *why) {
+const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_diag, std::string *why) {
   const int cells = N - 1;
   int wantM = 0, wantW = 0;
   if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
@@ -94,12 +99,13 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, std::strin
     const int cap = 64 * e.W * e.M;
     if (cap < cells) continue;
     if (e.full && !(cells == cap || cells == cap - 1)) continue;
+    if (!e.diag && (need_diag || general_only)) continue;
     if (e.bck == 0 && (usk == FS_BC_STORAGE_CURVE || dsk == FS_BC_STORAGE_CURVE)) continue;
     if (e.bck == 1 && (!light || sec != FS_SEC_RECT_UNIFORM)) continue;
     if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2 || general_only)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
-    auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0); };
+    auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
         (e.M == best->M && e.W == best->W && spec > bspec))
@@ -227,7 +233,7 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     return nullptr;
   }
   std::string why;
-  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, FS_BC_FLOW_HYDROGRAPH, FS_BC_FLOW_HYDROGRAPH, &why);
+  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, FS_BC_FLOW_HYDROGRAPH, FS_BC_FLOW_HYDROGRAPH, true, &why);
   if (!k) { fail("fs_batch_create: " + why); return nullptr; }
   fs_batch *b = new fs_batch();
   b->d = *desc;
@@ -454,7 +460,8 @@ int fs_batch_step(fs_batch *b, int32_t n_steps) {
   if (b->level + n_steps >= b->d.max_levels) return fail("fs_batch_step: would run past max_levels");
   HIP_TRY(hipSetDevice(b->d.device));
   {   // the boundary kinds are known now: prefer the variant with inlined boundary rows
-    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1], nullptr);
+    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
+                                 (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, nullptr);
     if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
       return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
     if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");

@@ -12,10 +12,10 @@
 
 typedef void (*FsLaunchFn)(const void *args, int B, hipStream_t st);
 
-template <typename R, int SEC, int M, int W, bool RAGGED, int BCK>
+template <typename R, int SEC, int M, int W, bool RAGGED, int BCK, bool DIAG = true>
 void fs_launch(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK>), dim3(B), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
 #define FS_LIST_RECT(X, R, DT) \
@@ -82,6 +82,17 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)
 
+// the hot shapes once more without the history / residual-trace stores (DIAG = false), for batches created without those flags
+#define FS_LIST_NODIAG(X) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 2, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
+  X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)) \
+  X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0)
+
 // explicit instantiation (fs_part_*.hip) / extern declaration (fs_abi.hip) of one entry
 #define FS_INSTANTIATE(R, DT, SEC, M, W, FULL, BCK)                                                            \
   template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>(const fs::KernelArgs<R>); \
@@ -89,3 +100,9 @@ void fs_launch(const void *args, int B, hipStream_t st) {
 #define FS_DECLARE(R, DT, SEC, M, W, FULL, BCK)                                                                       \
   extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>(const fs::KernelArgs<R>); \
   extern template void fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>(const void *, int, hipStream_t);
+#define FS_INSTANTIATE_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                                            \
+  template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false>(const fs::KernelArgs<R>); \
+  template void fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>(const void *, int, hipStream_t);
+#define FS_DECLARE_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                                                       \
+  extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false>(const fs::KernelArgs<R>); \
+  extern template void fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>(const void *, int, hipStream_t);

@@ -327,7 +327,9 @@ template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() 
   return FS_WPE_W1;
 }
 
-template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0>
+// DIAG = false: no per-level history and no residual trace (batches created without FS_FLAG_HISTORY / FS_FLAG_TRACE): the
+// stores are never executed there, but compiled in they cost the flagship kernel 1.1 %
+template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true>
 __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
@@ -680,7 +682,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       if (sm.xflag[parity] != 0) status = sm.xflag[parity];
       if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
       converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
-      if (a.trace && t == 0 && it <= FS_TRACE_CAP)
+      if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP)
         a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
 
       FS_T(5);
@@ -803,8 +805,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           // and, if a history is kept, at every level.  (A transposed, fully coalesced write-back
           // through LDS was measured too: no gain, three extra barriers.)
           const bool last = (step == a.n_steps - 1);
-          R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
-          R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          R *const hh_p = (DIAG && a.hist_h) ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          R *const hQ_p = (DIAG && a.hist_h) ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
           if (last || hh_p) {
 #pragma unroll
             for (int j = 0; j <= M; ++j) {

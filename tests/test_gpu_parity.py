@@ -554,6 +554,30 @@ def test_kernels_compiled_for_a_boundary_pair_match_the_general_ones(case, monke
     assert np.max(np.abs(hy_g - hy_p) / np.maximum(np.abs(hy_g), 1e-3)) <= 1e-13
 
 
+@pytest.mark.parametrize("case", ["synthetic_rect_512", "gerd", "irr_mixed", "trap_512"])
+def test_batches_without_history_run_the_same_numbers(case, monkeypatch):
+    """Batches created without FS_FLAG_HISTORY / FS_FLAG_TRACE get the instantiations compiled without those
+    stores (DIAG = false, fs_entries.hpp): same hydrographs to a few ulp, same iteration counts."""
+    from fixture_batch import batch_from_problems
+    if case.startswith("trap"):
+        probs, mode = _singular_pivot_problems(512, 5, 1e-6)[:3], "trap_uniform"
+    else:
+        _, _, probs = problems_of(os.path.join(GOLDEN, case + ".npz"))
+        mode = "auto"
+        if case in ("gerd", "irr_mixed"):
+            probs = probs[:1]
+            monkeypatch.setenv("FS_KERNEL_SHAPE", "2,1")
+    n = min(probs[0].nt - 1, 6)
+    out = []
+    for history in (True, False):
+        with batch_from_problems(probs, mode=mode, history=history) as b:
+            b.step(n)
+            assert np.all(b.status() == 0)
+            out.append((b.hydrographs(), b.iterations()))
+    assert np.array_equal(out[0][1], out[1][1])
+    assert np.max(np.abs(out[0][0] - out[1][0]) / np.maximum(np.abs(out[0][0]), 1e-3)) <= 1e-13
+
+
 def test_full_size_batch_properties():
     """BASELINE configs[2] size (65 536 reaches x 4 096 nodes, fp64) through size-independent
     properties: (i) 256 distinct channels replicated 256 times give bitwise identical copies,
