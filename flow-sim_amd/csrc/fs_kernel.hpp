@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #endif
       FS_T(4);
       const R err = sqrt_(tot);                                        // utility.py:20-22
-      if (sm.xflag[parity] != 0) status = sm.xflag[parity];
+      if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
       if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
       converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
       if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP)
