@@ -105,7 +105,9 @@ enum { FS_UPSTREAM = 0, FS_DOWNSTREAM = 1 };
 enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3 };
 
 enum {
-  FS_FLAG_HISTORY = 1,  /* keep depth/flow[level][B][N] on the device (solver.py:43-44) */
+  FS_FLAG_HISTORY = 1,  /* keep depth/flow[level][B][N] on the device (solver.py:43-44); large batches that only need the
+                           boundary hydrographs leave it (and FS_FLAG_TRACE) off: no [levels][B][N] arrays in HBM and
+                           step kernels compiled without those stores */
   FS_FLAG_TRACE = 2     /* keep ||R|| of every Newton iteration (what run(verbose=3) prints, preissmann.py:149-152) */
 };
 #define FS_TRACE_CAP 64 /* iterations per level kept by FS_FLAG_TRACE */
