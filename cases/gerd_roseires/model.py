@@ -32,11 +32,13 @@ class Scenario:
     # hydrology: inflow into GERD as a function of time, or - when None - as the table at inflow_hyd_path
     inflow_hyd_func: Optional[Callable] = settings.inflow_hyd_func
     inflow_hyd_path: str = settings.inflow_hyd_path
+    inflow_scale: float = 1.0                   # table inflow only: flood wave scaled about its base flow
     gerd_level: float = settings.initial_gerd_level
     with_gerd: bool = True                      # False: the inflow reaches the channel unregulated
     initial_roseires_level: float = settings.initial_roseires_level
     jammed_spillways: int = settings.JAMMED_SPILLWAYS
     jammed_sluice_gates: int = settings.JAMMED_SLUICEGATES
+    smooth_gates: bool = True                   # False: operated gates (time- and history-dependent: evaluated on the host)
     # geometry tables (coords_path None: straight channel, no curvature)
     coords_path: Optional[str] = settings.coords_path
     cross_sections_path: str = settings.cross_sections_path
@@ -52,8 +54,12 @@ def build(scenario: Scenario = None, **overrides):
         raise TypeError(f"unknown scenario parameter(s): {sorted(unknown)}")
     sc = replace(scenario or Scenario(), **overrides)
 
-    reservoir_inflow = Hydrograph(function=sc.inflow_hyd_func) if sc.inflow_hyd_func is not None \
-        else Hydrograph(table=import_hydrograph(sc.inflow_hyd_path))
+    if sc.inflow_hyd_func is not None:
+        reservoir_inflow = Hydrograph(function=sc.inflow_hyd_func)
+    else:
+        table = import_hydrograph(sc.inflow_hyd_path)
+        table[:, 1] = table[0, 1] + sc.inflow_scale * (table[:, 1] - table[0, 1])
+        reservoir_inflow = Hydrograph(table=table)
     if sc.sim_duration is not None:
         duration = int(sc.sim_duration)
     elif reservoir_inflow.table is not None:
@@ -71,7 +77,8 @@ def build(scenario: Scenario = None, **overrides):
     head = Boundary(condition='flow_hydrograph', chainage=stations[0],
                     hydrograph=release if sc.with_gerd else reservoir_inflow)
     gate_curve = RoseiresRatingCurve(initial_stage=sc.initial_roseires_level, initial_flow=q0,
-                                     jammed_spillways=sc.jammed_spillways, jammed_sluice_gates=sc.jammed_sluice_gates)
+                                     jammed_spillways=sc.jammed_spillways, jammed_sluice_gates=sc.jammed_sluice_gates,
+                                     smooth=sc.smooth_gates)
     dam = Boundary(condition='rating_curve', rating_curve=gate_curve, chainage=stations[-1], bed_level=z_dam,
                    initial_depth=sc.initial_roseires_level - z_dam)
 

@@ -7,8 +7,15 @@ everything open, and the discharge blends from one to the other with a smoothste
 metres above the initial stage (semantics of the reference's
 cases/gerd_roseires/roseires_rating_curve.py:18-257 with smooth=True, its default).
 
-For a fixed gate state both releases are quadratics in the stage, so the curve has an exact
-device form: FS_BC_RATING_BLEND (`device_spec`)."""
+For a fixed gate state both releases are quadratics in the stage, so the smooth curve has an exact
+device form: FS_BC_RATING_BLEND (`device_spec`).
+
+smooth=False is the reference's operated-gate mode (roseires_rating_curve.py:65-78, :111-140): the
+gates open once the stage seen by the previous call has risen `0.5 m` above the initial stage and
+close once it has fallen 1 m below it, with a cool-down in simulation time between two moves.  That
+curve depends on time and on its own history, so it has no device form: device_spec() raises
+NotImplementedError and PreissmannSolver.run evaluates the boundary row on the host every Newton
+iteration (FS_BC_HOST_ROW)."""
 import numpy as np
 from scipy.optimize import brentq
 
@@ -45,21 +52,23 @@ def stage_quadratic(model, x1):
 
 class RoseiresRatingCurve(RatingCurve):
     def __init__(self, initial_stage=None, initial_flow=None, initially_open=False, jammed_spillways=0,
-                 jammed_sluice_gates=0, smooth=True, buffer=0.5, deep_sluices_active=True):
+                 jammed_sluice_gates=0, max_cooldown=3600 * 5, smooth=True, buffer=0.5, deep_sluices_active=True):
         super().__init__()
-        if not smooth:
-            raise NotImplementedError("only the smooth (default) gate transition has a device form")
         if initial_stage > MAX_STAGE or initial_stage < MIN_STAGE:
             raise ValueError(f"Roseires water stage must be between {MIN_STAGE} m and {MAX_STAGE} m.")
         self.spillway_model = fit_quadratic_surface(*grid_table(settings.spillway_table_path))
         self.sluice_model = fit_quadratic_surface(*grid_table(settings.sluice_table_path))
-        self.initial_stage, self.buffer, self.smooth = initial_stage, buffer, True
+        self.initial_stage, self.buffer, self.smooth = initial_stage, buffer, bool(smooth)
         self.tail_water_level = float(np.average(TAIL_WATER_LEVEL_RANGE))
         n_sp = NUM_SPILLWAYS - jammed_spillways
         n_sl = NUM_SLUICE_GATES - (jammed_sluice_gates if deep_sluices_active else NUM_SLUICE_GATES)
         self.open_state = ([MAX_SPILLWAY_OPENING] * n_sp + [0] * jammed_spillways, n_sl)
         self.closed_state = self._closed_state(initial_flow, n_sp, n_sl)
         self.defined, self.type = True, "blend"
+        # operated gates (smooth=False): position, stage seen by the last evaluation, cool-down clock
+        self.open = bool(initially_open)
+        self.current_stage = initial_stage
+        self.max_cooldown, self.cooldown, self.prev_time = max_cooldown, 0, None
 
     # ---- releases -----------------------------------------------------------------------------
     def total_release(self, stage, state):
@@ -100,12 +109,32 @@ class RoseiresRatingCurve(RatingCurve):
         s = (stage - s0) / buf
         return 3 * s ** 2 - 2 * s ** 3
 
-    def discharge(self, stage, time=None, **_):
-        w = self.blend_weight(stage)
-        return (1.0 - w) * self.total_release(stage, self.closed_state) + w * self.total_release(stage, self.open_state)
+    def gate_control(self, time):
+        """moves the gates at most once per cool-down period (roseires_rating_curve.py:111-133)"""
+        if self.prev_time is not None:
+            self.cooldown = max(0, self.cooldown - (time - self.prev_time))
+        self.prev_time = time
+        if self.cooldown > 0:
+            return
+        if not self.open and self.current_stage >= self.initial_stage + 0.5:
+            self.cooldown, self.open = self.max_cooldown, True
+        elif self.open and self.current_stage <= self.initial_stage - 1:
+            self.cooldown, self.open = self.max_cooldown, False
+
+    def discharge(self, stage, time=None, update_stage=True, update_gate_state=True, smooth=None):
+        if self.smooth if smooth is None else smooth:
+            w = self.blend_weight(stage)
+            return (1.0 - w) * self.total_release(stage, self.closed_state) + w * self.total_release(stage, self.open_state)
+        if update_gate_state:
+            self.gate_control(time=time)
+        q = self.total_release(stage, self.open_state if self.open else self.closed_state)
+        if update_stage:
+            self.current_stage = stage
+        return q
 
     def dQ_dz(self, stage, time=None, dY=0.001):
-        return (self.discharge(stage + dY) - self.discharge(stage - dY)) / (2 * dY)
+        hold = dict(time=time, update_stage=False, update_gate_state=False)
+        return (self.discharge(stage + dY, **hold) - self.discharge(stage - dY, **hold)) / (2 * dY)
 
     # ---- device form -----------------------------------------------------------------------------
     def _state_quadratic(self, state):
@@ -118,6 +147,8 @@ class RoseiresRatingCurve(RatingCurve):
         return q
 
     def device_spec(self, bed_level):
+        if not self.smooth:
+            raise NotImplementedError("operated gates (smooth=False) depend on time and on their own history: evaluated on the host")
         lo, hi = self._state_quadratic(self.closed_state), self._state_quadratic(self.open_state)
         return "blend", dict(stage0=self.initial_stage, buffer=self.buffer, lo0=lo[0], lo1=lo[1], lo2=lo[2],
                              hi0=hi[0], hi1=hi[1], hi2=hi[2], dY=0.001, bed_level=bed_level)

@@ -38,6 +38,21 @@ int fail(const std::string &m) { g_err = m; return -1; }
 
 struct Shape { int M, W; };
 
+// Every entry point that allocates, copies, launches or frees runs with the batch's device current and puts the
+// caller's device back on the way out (two batches on different ordinals in one process, calls from another thread).
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+#define FS_ON_DEVICE(b)                                                                     \
+  DeviceGuard guard_((b)->d.device);                                                        \
+  if (!guard_.ok) return fail("hipSetDevice(" + std::to_string((b)->d.device) + ") failed")
+
 typedef FsLaunchFn LaunchFn;
 typedef const void *KernelPtr;
 
@@ -86,23 +101,41 @@ const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRA
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
 // choice for experiments and tests.
-const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_diag, std::string *why) {
+constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
+
+bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, bool need_diag, bool need_any) {
   const int cells = N - 1;
+  const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
+  const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
+  if (e.dtype != dtype || e.sec != sec) return false;
+  const int cap = 64 * e.W * e.M;
+  if (cap < cells) return false;
+  if (e.full && !(cells == cap || cells == cap - 1)) return false;
+  if (!e.diag && need_diag) return false;
+  if (need_any && e.bck != -1) return false;
+  if (e.bck == 0 && beyond0) return false;
+  if (e.bck == 1 && (!light || sec != FS_SEC_RECT_UNIFORM)) return false;
+  if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2)) return false;
+  return true;
+}
+
+// need_any: the caller needs a kernel of boundary class -1 (iteration budget, host rows)
+const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_diag, std::string *why, bool need_any = false,
+                         bool honour_index = true) {
+  if (const char *env = honour_index ? std::getenv("FS_KERNEL_INDEX") : nullptr) {      // tests: one specific instantiation or nothing
+    const int i = std::atoi(env);
+    if (i >= 0 && i < kNumEntries && entry_fits(kEntries[i], dtype, sec, N, usk, dsk, need_diag, need_any)) return &kEntries[i];
+    if (why) *why = "FS_KERNEL_INDEX=" + std::string(env) + " does not fit this batch";
+    return nullptr;
+  }
   int wantM = 0, wantW = 0;
   if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
   const char *gen = std::getenv("FS_KERNEL_GENERAL");
   const bool general_only = gen && gen[0] == '1';
-  const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const Entry *best = nullptr;
   for (const Entry &e : kEntries) {
-    if (e.dtype != dtype || e.sec != sec) continue;
-    const int cap = 64 * e.W * e.M;
-    if (cap < cells) continue;
-    if (e.full && !(cells == cap || cells == cap - 1)) continue;
-    if (!e.diag && (need_diag || general_only)) continue;
-    if (e.bck == 0 && (usk == FS_BC_STORAGE_CURVE || dsk == FS_BC_STORAGE_CURVE)) continue;
-    if (e.bck == 1 && (!light || sec != FS_SEC_RECT_UNIFORM)) continue;
-    if (e.bck >= 2 && (usk != FS_BC_FLOW_HYDROGRAPH || dsk != e.bck - 2 || general_only)) continue;
+    if (!entry_fits(e, dtype, sec, N, usk, dsk, need_diag, need_any)) continue;
+    if (general_only && (!e.diag || e.bck >= 2)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
     auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8); };
@@ -123,6 +156,7 @@ struct fs_batch {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timed = false;
+  bool iterating = false;     // a level opened by fs_batch_iterate has not been closed yet
   int launches = 0;
   int level = 0;
   const Entry *kern = nullptr;
@@ -139,6 +173,9 @@ struct fs_batch {
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
   void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
   int32_t *iters = nullptr, *status = nullptr;
+  int32_t *it_done = nullptr;          // [B] Newton iterations spent on the open level (fs_batch_iterate)
+  void *derived[8] = {nullptr};        // device results of the last derive call, kept and reused
+  size_t derived_cap[8] = {0};         // their capacities in elements
   unsigned long long *dbg = nullptr;
 };
 
@@ -198,6 +235,33 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.trace = (R *)b->trace; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
   a.dbg = b->dbg;
+  a.iter_budget = 0; a.it_done = b->it_done;
+}
+
+// picks the instantiation for the batch as it is now (the boundary kinds are known) and launches it on the handle's stream
+int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
+  std::string why;
+  const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
+                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, &why, iter_budget > 0);
+  if (!k && why.rfind("FS_KERNEL_INDEX", 0) == 0) return fail("fs_batch_step: " + why);
+  if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
+    return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
+  if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
+  b->kern = k;
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  if (b->d.dtype == FS_F64) {
+    fs::KernelArgs<double> a; fill_args(b, n_steps, a);
+    a.iter_budget = iter_budget;
+    b->kern->fn(&a, b->d.n_reaches, b->stream);
+  } else {
+    fs::KernelArgs<float> a; fill_args(b, n_steps, a);
+    a.iter_budget = iter_budget;
+    b->kern->fn(&a, b->d.n_reaches, b->stream);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  b->timed = true; b->launches = 1;
+  return 0;
 }
 
 }  // namespace
@@ -233,15 +297,19 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
     return nullptr;
   }
   std::string why;
-  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, FS_BC_FLOW_HYDROGRAPH, FS_BC_FLOW_HYDROGRAPH, true, &why);
+  const Entry *k = pick_kernel(desc->dtype, desc->section_mode, desc->n_nodes, FS_BC_FLOW_HYDROGRAPH, FS_BC_FLOW_HYDROGRAPH, true, &why,
+                               false, false);
   if (!k) { fail("fs_batch_create: " + why); return nullptr; }
   fs_batch *b = new fs_batch();
   b->d = *desc;
   b->esz = desc->dtype == FS_F64 ? 8 : 4;
   b->kern = k;
+  int prev_dev = -1;
+  if (hipGetDevice(&prev_dev) != hipSuccess) prev_dev = -1;
   auto bad = [&](const char *what, hipError_t e) {
     fail(std::string("fs_batch_create: ") + what + ": " + hipGetErrorString(e));
     fs_batch_destroy(b);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);
     return (fs_batch *)nullptr;
   };
   hipError_t e;
@@ -258,10 +326,12 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc((void **)&b->status, B * 4)) != hipSuccess) return bad("hipMalloc(status)", e);
   if ((e = hipMalloc(&b->Yprev, B * b->esz)) != hipSuccess) return bad("hipMalloc(Yprev)", e);
   if ((e = hipMalloc(&b->stage_hist, L * B * b->esz)) != hipSuccess) return bad("hipMalloc(stage_hist)", e);
-  (void)hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream);
+  if ((e = hipMalloc((void **)&b->it_done, B * 4)) != hipSuccess) return bad("hipMalloc(it_done)", e);
+  if ((e = hipMemsetAsync(b->stage_hist, 0, L * B * b->esz, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
+  if ((e = hipMemsetAsync(b->it_done, 0, B * 4, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
   if (desc->flags & FS_FLAG_TRACE) {
     if ((e = hipMalloc(&b->trace, L * FS_TRACE_CAP * B * b->esz)) != hipSuccess) return bad("hipMalloc(trace)", e);
-    (void)hipMemsetAsync(b->trace, 0, L * FS_TRACE_CAP * B * b->esz, b->stream);
+    if ((e = hipMemsetAsync(b->trace, 0, L * FS_TRACE_CAP * B * b->esz, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
   }
   if (desc->flags & FS_FLAG_HISTORY) {
     if ((e = hipMalloc(&b->hist_h, L * B * N * b->esz)) != hipSuccess) return bad("hipMalloc(history)", e);
@@ -271,21 +341,24 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMalloc((void **)&b->dbg, B * 16 * 12 * 8)) != hipSuccess) return bad("hipMalloc(dbg)", e);
   hipMemsetAsync(b->dbg, 0, B * 16 * 12 * 8, b->stream);
 #endif
-  (void)hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream);
-  (void)hipMemsetAsync(b->iters, 0, L * B * 4, b->stream);
-  (void)hipMemsetAsync(b->status, 0, B * 4, b->stream);
-  (void)hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream);
-  (void)hipStreamSynchronize(b->stream);
+  if ((e = hipMemsetAsync(b->hydro, 0, L * 4 * B * b->esz, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
+  if ((e = hipMemsetAsync(b->iters, 0, L * B * 4, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
+  if ((e = hipMemsetAsync(b->status, 0, B * 4, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
+  if ((e = hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
+  if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return bad("hipStreamSynchronize", e);
+  (void)hipSetDevice(prev_dev >= 0 ? prev_dev : desc->device);
   return b;
 }
 
 void fs_batch_destroy(fs_batch *b) {
   if (!b) return;
+  DeviceGuard guard_(b->d.device);
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
-                  b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n};
+                  b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg};
   for (void *p : bufs) if (p) (void)hipFree(p);
+  for (void *p : b->derived) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -303,6 +376,7 @@ int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double 
 int fs_batch_set_geometry_uniform(fs_batch *b, const double *params) {
   if (!b || !params) return fail("fs_batch_set_geometry_uniform: null argument");
   const bool trap = b->d.section_mode == FS_SEC_TRAP_UNIFORM;
+  FS_ON_DEVICE(b);
   if (b->d.section_mode != FS_SEC_RECT_UNIFORM && !trap) return fail("fs_batch_set_geometry_uniform: batch was created with another section_mode");
   const size_t B = b->d.n_reaches;
   for (size_t i = 0; i < B; ++i) {
@@ -318,6 +392,7 @@ int fs_batch_set_geometry_uniform(fs_batch *b, const double *params) {
 int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *n_main_override) {
   if (!b || !table) return fail("fs_batch_set_geometry_table: null argument");
   if (b->d.section_mode != FS_SEC_TABLE) return fail("fs_batch_set_geometry_table: batch was created with another section_mode");
+  FS_ON_DEVICE(b);
   if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * b->d.n_nodes)) return -1;
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
@@ -334,6 +409,7 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
   if (!b || !table || !n_pts || !x || !z || !limits) return fail("fs_batch_set_geometry_irregular: null argument");
   if (b->d.section_mode != FS_SEC_IRREGULAR) return fail("fs_batch_set_geometry_irregular: batch was created with another section_mode");
   if (max_pts < 2) return fail("fs_batch_set_geometry_irregular: max_pts must be >= 2");
+  FS_ON_DEVICE(b);
   const size_t N = b->d.n_nodes, P = max_pts;
   // vertex-major copies [P][N]; unused slots repeat the last vertex so that no lane ever reads NaN
   std::vector<double> xt(P * N, 0.0), zt(P * N, 0.0), lim(2 * N, 0.0);
@@ -376,8 +452,24 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
                     int32_t per_reach, const double *target) {
   if (!b) return fail("null handle");
   if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: side must be FS_UPSTREAM or FS_DOWNSTREAM");
+  FS_ON_DEVICE(b);
   static const int need[] = {0, 1, 1, 2, 4, 5, 10, 5};
-  if (kind < 0 || kind > FS_BC_STORAGE_CURVE) return fail("Invalid boundary condition.");        // boundary.py:33
+  if (kind < 0 || kind > FS_BC_HOST_ROW) return fail("Invalid boundary condition.");        // boundary.py:33
+  if (kind == FS_BC_HOST_ROW) {
+    if (b->d.section_mode != FS_SEC_TABLE && b->d.section_mode != FS_SEC_IRREGULAR)
+      return fail("fs_batch_set_bc: FS_BC_HOST_ROW needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
+    if (n_params != 3 || !per_reach) return fail("fs_batch_set_bc: FS_BC_HOST_ROW takes params[3][B] (per_reach = 1) or NULL");
+    const size_t B = b->d.n_reaches;
+    if (b->bc_params[side]) { (void)hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
+    if (b->bc_target[side]) { (void)hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
+    if (params) { if (upload(b, &b->bc_params[side], params, 3 * B)) return -1; }
+    else {
+      HIP_TRY(hipMalloc(&b->bc_params[side], 3 * B * b->esz));
+      HIP_TRY(hipMemsetAsync(b->bc_params[side], 0, 3 * B * b->esz, b->stream));
+    }
+    b->bc_kind[side] = kind; b->bc_stride[side] = 1; b->have_bc[side] = true;
+    return 0;
+  }
   if (kind == FS_BC_STORAGE_CURVE) {
     if (per_reach) return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE parameters are shared by the batch (per_reach = 0)");
     if (!params || n_params < FS_SC_NFIXED) return fail("Insufficient arguments for boundary condition.");
@@ -405,6 +497,7 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
 
 int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_set_state: null argument");
+  FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches, N = b->d.n_nodes;
   if (upload(b, &b->hk, h, B * N) || upload(b, &b->Qk, Q, B * N) || upload(b, &b->hg, h, B * N) || upload(b, &b->Qg, Q, B * N)) return -1;
   if (b->hist_h) {   // level 0 of the history = initial conditions (solver.py:61-63)
@@ -422,15 +515,18 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
   if (b->trace) HIP_TRY(hipMemsetAsync(b->trace, 0, (size_t)b->d.max_levels * FS_TRACE_CAP * B * b->esz, b->stream));
-  b->level = 0;
+  HIP_TRY(hipMemsetAsync(b->it_done, 0, B * 4, b->stream));
+  b->level = 0; b->iterating = false;
   b->have_state = true;
   return 0;
 }
 
 int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_set_state_uniform: null argument");
+  FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches, N = b->d.n_nodes;
   void *dh = nullptr, *dQ = nullptr;
+  struct Tmp { void *&a, *&c; ~Tmp() { if (a) (void)hipFree(a); if (c) (void)hipFree(c); } } tmp_{dh, dQ};
   if (upload(b, &dh, h, B) || upload(b, &dQ, Q, B)) return -1;
   const dim3 grid((unsigned)((B * N + 255) / 256));
   if (b->d.dtype == FS_F64)
@@ -445,8 +541,9 @@ int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->status, 0, B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->iters, 0, (size_t)b->d.max_levels * B * 4, b->stream));
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
+  HIP_TRY(hipMemsetAsync(b->it_done, 0, B * 4, b->stream));
+  if (b->trace) HIP_TRY(hipMemsetAsync(b->trace, 0, (size_t)b->d.max_levels * FS_TRACE_CAP * B * b->esz, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  (void)hipFree(dh); (void)hipFree(dQ);
   b->level = 0;
   b->have_state = true;
   return 0;
@@ -458,32 +555,89 @@ int fs_batch_step(fs_batch *b, int32_t n_steps) {
     return fail("fs_batch_step: scheme, geometry, both boundaries and the initial state must be set first");
   if (n_steps < 1) return fail("fs_batch_step: n_steps must be >= 1");
   if (b->level + n_steps >= b->d.max_levels) return fail("fs_batch_step: would run past max_levels");
-  HIP_TRY(hipSetDevice(b->d.device));
-  {   // the boundary kinds are known now: prefer the variant with inlined boundary rows
-    const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
-                                 (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, nullptr);
-    if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
-      return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
-    if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
-    b->kern = k;
-  }
-  HIP_TRY(hipEventRecord(b->ev0, b->stream));
-  if (b->d.dtype == FS_F64) {
-    fs::KernelArgs<double> a; fill_args(b, n_steps, a);
-    b->kern->fn(&a, b->d.n_reaches, b->stream);
-  } else {
-    fs::KernelArgs<float> a; fill_args(b, n_steps, a);
-    b->kern->fn(&a, b->d.n_reaches, b->stream);
-  }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(b->ev1, b->stream));
-  b->timed = true; b->launches = 1;
+  if (b->bc_kind[0] == FS_BC_HOST_ROW || b->bc_kind[1] == FS_BC_HOST_ROW)
+    return fail("fs_batch_step: a batch with FS_BC_HOST_ROW boundaries advances with fs_batch_iterate (the caller evaluates the rows "
+                "before every Newton iteration)");
+  if (b->iterating) return fail("fs_batch_step: a level opened with fs_batch_iterate must be closed with it first");
+  FS_ON_DEVICE(b);
+  if (launch_steps(b, n_steps, 0)) return -1;
   b->level += n_steps;
+  return 0;
+}
+
+int fs_batch_iterate(fs_batch *b, int32_t *n_open) {
+  if (!b) return fail("null handle");
+  if (!b->have_scheme || !b->have_geo || !b->have_state || !b->have_bc[0] || !b->have_bc[1])
+    return fail("fs_batch_iterate: scheme, geometry, both boundaries and the initial state must be set first");
+  if (b->level + 1 >= b->d.max_levels) return fail("fs_batch_iterate: would run past max_levels");
+  if (b->d.section_mode != FS_SEC_TABLE && b->d.section_mode != FS_SEC_IRREGULAR)
+    return fail("fs_batch_iterate: section mode FS_SEC_TABLE or FS_SEC_IRREGULAR required");
+  FS_ON_DEVICE(b);
+  if (launch_steps(b, 1, 1)) return -1;
+  b->iterating = true;
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const size_t B = b->d.n_reaches;
+  std::vector<int32_t> done(B), st(B);
+  HIP_TRY(hipMemcpy(done.data(), b->it_done, B * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(st.data(), b->status, B * 4, hipMemcpyDeviceToHost));
+  int32_t open = 0;
+  for (size_t r = 0; r < B; ++r) open += (done[r] >= 0 && st[r] == FS_OK) ? 1 : 0;
+  if (open == 0) {      // every reach has accepted the level (or failed on it): next level, counters back to zero
+    b->level += 1;
+    b->iterating = false;
+    HIP_TRY(hipMemsetAsync(b->it_done, 0, B * 4, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  if (n_open) *n_open = open;
+  return 0;
+}
+
+int fs_batch_set_host_rows(fs_batch *b, int32_t side, const double *rows) {
+  if (!b || !rows) return fail("fs_batch_set_host_rows: null argument");
+  if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_host_rows: side must be FS_UPSTREAM or FS_DOWNSTREAM");
+  if (!b->have_bc[side] || b->bc_kind[side] != FS_BC_HOST_ROW) return fail("fs_batch_set_host_rows: this side is not an FS_BC_HOST_ROW boundary");
+  FS_ON_DEVICE(b);
+  return upload(b, &b->bc_params[side], rows, (size_t)3 * b->d.n_reaches);
+}
+
+int fs_batch_get_boundary_iterate(fs_batch *b, double *out) {
+  if (!b || !out) return fail("fs_batch_get_boundary_iterate: null argument");
+  if (!b->have_state) return fail("fs_batch_get_boundary_iterate: no state yet");
+  FS_ON_DEVICE(b);
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes, e = b->esz;
+  std::vector<char> tmp(4 * B * e);
+  const void *src[4] = {b->hg, b->Qg, (const char *)b->hg + (N - 1) * e, (const char *)b->Qg + (N - 1) * e};
+  for (int i = 0; i < 4; ++i)      // one element per reach: a strided copy (rows of N elements, one column)
+    HIP_TRY(hipMemcpy2D(tmp.data() + (size_t)i * B * e, e, src[i], N * e, e, B, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < 4 * B; ++i) out[i] = e == 8 ? ((const double *)tmp.data())[i] : (double)((const float *)tmp.data())[i];
+  return 0;
+}
+
+int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *Q, const double *h_guess, const double *Q_guess,
+                     const double *storage_stage) {
+  if (!b || !h || !Q || !h_guess || !Q_guess) return fail("fs_batch_restart: null argument");
+  if (level < 0 || level + 1 >= b->d.max_levels) return fail("fs_batch_restart: level out of range");
+  if (fs_batch_set_state(b, h, Q)) return -1;
+  FS_ON_DEVICE(b);
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes;
+  if (upload(b, &b->hg, h_guess, B * N) || upload(b, &b->Qg, Q_guess, B * N)) return -1;
+  if (storage_stage && upload(b, &b->Yprev, storage_stage, B)) return -1;
+  if (level > 0) {     // the boundary row of `level` (fs_batch_set_state wrote it to row 0) moves to its own row
+    HIP_TRY(hipMemcpyAsync((char *)b->hydro + (size_t)level * 4 * B * b->esz, b->hydro, 4 * B * b->esz, hipMemcpyDeviceToDevice, b->stream));
+    if (b->hist_h) {
+      HIP_TRY(hipMemcpyAsync((char *)b->hist_h + (size_t)level * B * N * b->esz, b->hist_h, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
+      HIP_TRY(hipMemcpyAsync((char *)b->hist_Q + (size_t)level * B * N * b->esz, b->hist_Q, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+  }
+  b->level = level;
   return 0;
 }
 
 int fs_batch_sync(fs_batch *b) {
   if (!b) return fail("null handle");
+  FS_ON_DEVICE(b);
   HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -492,18 +646,21 @@ int32_t fs_batch_level(const fs_batch *b) { return b ? b->level : -1; }
 
 int fs_batch_get_state(fs_batch *b, double *h, double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_get_state: null argument");
+  FS_ON_DEVICE(b);
   const size_t n = (size_t)b->d.n_reaches * b->d.n_nodes;
   return download(b, h, b->hk, 0, n) || download(b, Q, b->Qk, 0, n) ? -1 : 0;
 }
 
 int fs_batch_get_guess(fs_batch *b, double *h, double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_get_guess: null argument");
+  FS_ON_DEVICE(b);
   const size_t n = (size_t)b->d.n_reaches * b->d.n_nodes;
   return download(b, h, b->hg, 0, n) || download(b, Q, b->Qg, 0, n) ? -1 : 0;
 }
 
 int fs_batch_get_hydrographs(fs_batch *b, int32_t first, int32_t n, double *out) {
   if (!b || !out) return fail("fs_batch_get_hydrographs: null argument");
+  FS_ON_DEVICE(b);
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_hydrographs: level range out of bounds");
   const size_t B = b->d.n_reaches;
   return download(b, out, b->hydro, (size_t)first * 4 * B, (size_t)n * 4 * B);
@@ -511,6 +668,7 @@ int fs_batch_get_hydrographs(fs_batch *b, int32_t first, int32_t n, double *out)
 
 int fs_batch_get_iterations(fs_batch *b, int32_t first, int32_t n, int32_t *out) {
   if (!b || !out) return fail("fs_batch_get_iterations: null argument");
+  FS_ON_DEVICE(b);
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_iterations: level range out of bounds");
   const size_t B = b->d.n_reaches;
   HIP_TRY(hipStreamSynchronize(b->stream));
@@ -520,6 +678,7 @@ int fs_batch_get_iterations(fs_batch *b, int32_t first, int32_t n, int32_t *out)
 
 int fs_batch_get_status(fs_batch *b, int32_t *out) {
   if (!b || !out) return fail("fs_batch_get_status: null argument");
+  FS_ON_DEVICE(b);
   HIP_TRY(hipStreamSynchronize(b->stream));
   HIP_TRY(hipMemcpy(out, b->status, (size_t)b->d.n_reaches * 4, hipMemcpyDeviceToHost));
   return 0;
@@ -527,6 +686,7 @@ int fs_batch_get_status(fs_batch *b, int32_t *out) {
 
 int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_get_history: null argument");
+  FS_ON_DEVICE(b);
   if (!b->hist_h) return fail("fs_batch_get_history: batch was created without FS_FLAG_HISTORY");
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_history: level range out of bounds");
   const size_t per = (size_t)b->d.n_reaches * b->d.n_nodes;
@@ -535,11 +695,13 @@ int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, doubl
 
 int fs_batch_get_storage_stage(fs_batch *b, double *out) {
   if (!b || !out) return fail("fs_batch_get_storage_stage: null argument");
+  FS_ON_DEVICE(b);
   return download(b, out, b->Yprev, 0, b->d.n_reaches);
 }
 
 int fs_batch_get_residual_trace(fs_batch *b, int32_t first, int32_t n, double *out) {
   if (!b || !out) return fail("fs_batch_get_residual_trace: null argument");
+  FS_ON_DEVICE(b);
   if (!b->trace) return fail("fs_batch_get_residual_trace: batch was created without FS_FLAG_TRACE");
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_residual_trace: level range out of bounds");
   const size_t per = (size_t)FS_TRACE_CAP * b->d.n_reaches;
@@ -548,48 +710,69 @@ int fs_batch_get_residual_trace(fs_batch *b, int32_t first, int32_t n, double *o
 
 int fs_batch_get_storage_stages(fs_batch *b, int32_t first, int32_t n, double *out) {
   if (!b || !out) return fail("fs_batch_get_storage_stages: null argument");
+  FS_ON_DEVICE(b);
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_storage_stages: level range out of bounds");
   const size_t B = b->d.n_reaches;
   return download(b, out, b->stage_hist, (size_t)first * B, (size_t)n * B);
 }
 
-int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double *area, double *top_width,
-                    double *froude, double *velocity, double *celerity, double *amplitude, double *peak_amplitude) {
+int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields) {
   if (!b) return fail("null handle");
   if (!b->hist_h) return fail("fs_batch_derive: batch was created without FS_FLAG_HISTORY");
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_derive: level range out of bounds");
+  if ((fields & FS_DERIVE_ALL) == 0) return fail("fs_batch_derive: no field requested");
+  FS_ON_DEVICE(b);
   const size_t BN = (size_t)b->d.n_reaches * b->d.n_nodes;
-  double *host[8] = {level, area, top_width, froude, velocity, celerity, amplitude, peak_amplitude};
   void *dev[8] = {nullptr};
-  int rc = 0;
-  for (int f = 0; f < 8 && !rc; ++f)
-    if (host[f] && hipMalloc(&dev[f], (f == 7 ? BN : BN * n) * b->esz) != hipSuccess) rc = fail("fs_batch_derive: hipMalloc failed");
-  if (!rc) {
-    const dim3 grid((unsigned)((BN + 255) / 256));
-    (void)hipEventRecord(b->ev0, b->stream);      // fs_batch_last_step_ms() then reports this kernel
-    if (b->d.dtype == FS_F64) {
-      fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
-                               (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
-                               (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
-                               (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
-                               (double *)dev[5], (double *)dev[6], (double *)dev[7]};
-      hipLaunchKernelGGL((fs::derive_fields_kernel<double>), grid, dim3(256), 0, b->stream, a);
-    } else {
-      fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
-                              (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
-                              (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
-                              (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
-                              (float *)dev[5], (float *)dev[6], (float *)dev[7]};
-      hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);
+  for (int f = 0; f < 8; ++f) {
+    if (!(fields & (1 << f))) continue;
+    const size_t need = f == 7 ? BN : BN * n;
+    if (b->derived_cap[f] < need) {          // grown, never shrunk: a later call of the same size allocates nothing
+      if (b->derived[f]) { (void)hipFree(b->derived[f]); b->derived[f] = nullptr; b->derived_cap[f] = 0; }
+      HIP_TRY(hipMalloc(&b->derived[f], need * b->esz));
+      b->derived_cap[f] = need;
     }
-    (void)hipEventRecord(b->ev1, b->stream);
-    b->timed = true; b->launches = 1;
-    if (hipGetLastError() != hipSuccess) rc = fail("fs_batch_derive: launch failed");
-    for (int f = 0; f < 8 && !rc; ++f)
-      if (host[f]) rc = download(b, host[f], dev[f], 0, f == 7 ? BN : BN * n);
+    dev[f] = b->derived[f];
   }
-  for (void *p : dev) if (p) (void)hipFree(p);
-  return rc;
+  const dim3 grid((unsigned)((BN + 255) / 256));
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));      // fs_batch_last_step_ms() then reports this kernel
+  if (b->d.dtype == FS_F64) {
+    fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
+                             (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
+                             (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
+                             (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
+                             (double *)dev[5], (double *)dev[6], (double *)dev[7]};
+    hipLaunchKernelGGL((fs::derive_fields_kernel<double>), grid, dim3(256), 0, b->stream, a);
+  } else {
+    fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
+                            (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
+                            (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
+                            (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
+                            (float *)dev[5], (float *)dev[6], (float *)dev[7]};
+    hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  b->timed = true; b->launches = 1;
+  return 0;
+}
+
+void *fs_batch_derived_device_ptr(fs_batch *b, int32_t field_index) {
+  return (b && field_index >= 0 && field_index < 8) ? b->derived[field_index] : nullptr;
+}
+
+int fs_batch_derive(fs_batch *b, int32_t first, int32_t n, double *level, double *area, double *top_width,
+                    double *froude, double *velocity, double *celerity, double *amplitude, double *peak_amplitude) {
+  if (!b) return fail("null handle");
+  double *host[8] = {level, area, top_width, froude, velocity, celerity, amplitude, peak_amplitude};
+  int fields = 0;
+  for (int f = 0; f < 8; ++f) fields |= host[f] ? (1 << f) : 0;
+  if (fs_batch_derive_device(b, first, n, fields)) return -1;
+  FS_ON_DEVICE(b);
+  const size_t BN = (size_t)b->d.n_reaches * b->d.n_nodes;
+  for (int f = 0; f < 8; ++f)
+    if (host[f] && download(b, host[f], b->derived[f], 0, f == 7 ? BN : BN * n)) return -1;
+  return 0;
 }
 
 void *fs_batch_hydrograph_device_ptr(fs_batch *b) { return b ? b->hydro : nullptr; }
@@ -614,6 +797,17 @@ int fs_debug_stamps(fs_batch *b, unsigned long long *out) {
   return 0;
 }
 #endif
+
+int32_t fs_kernel_table_size(void) { return kNumEntries; }
+
+int fs_kernel_table_entry(int32_t i, int32_t *out) {
+  if (i < 0 || i >= kNumEntries || !out) return fail("fs_kernel_table_entry: index out of range");
+  const Entry &e = kEntries[i];
+  out[0] = e.dtype; out[1] = e.sec; out[2] = e.M; out[3] = e.W; out[4] = e.full; out[5] = e.bck; out[6] = e.diag; out[7] = 0;
+  return 0;
+}
+
+int32_t fs_batch_kernel_index(fs_batch *b) { return (b && b->kern) ? (int32_t)(b->kern - kEntries) : -1; }
 
 int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach, int32_t *lds_bytes,
                          int32_t *vgprs) {

@@ -610,6 +610,11 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
       return bc_storage_curve(bc, reach, B, level, entry_props(general_props_call(sec, h)),
                               entry_props(general_props_call(sec, h + bed - sec.z)), h, Q, Qold, dt, Yprev, Ynew, flag);
     }
+    case FS_BC_HOST_ROW:
+      // the row was evaluated by the caller at this Newton vector (fs_batch_set_host_rows; kernels of class -1 only)
+      if (WITH_SC) { r.dh = p(0); r.dq = p(1); r.res = p(2); }
+      else { r.res = R(0); r.dh = R(1); r.dq = R(0); }
+      break;
     default:
       r.res = R(0); r.dh = R(1); r.dq = R(0); break;
   }
@@ -621,7 +626,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
 // state around it).  Only the kinds that need no pow() are inlined (bc_is_light): the power rating
 // curve drags ~50 SGPR constants and ~300 instructions of pow() into the hot loop otherwise.
 // zsec = bed level of the boundary node's section.
-__host__ __device__ constexpr bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind != FS_BC_STORAGE_CURVE; }
+__host__ __device__ constexpr bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind < FS_BC_STORAGE_CURVE; }
 
 // lp: this reach's parameters in LDS (typed pointer: ds_read, not a flat load through a generic one)
 template <typename R> using LdsParams = const __attribute__((address_space(3))) R *;

@@ -98,8 +98,12 @@ namespace fs {
 #define FS_T(i) do { } while (0)
 #endif
 
+template <typename R> __host__ __device__ constexpr R huge_norm() { return sizeof(R) == 8 ? R(1e300) : R(3.0e38); }
+
 template <typename R> struct KernelArgs {
   int32_t B, N, n_steps, level0, max_iter;
+  int32_t iter_budget;     // kernels of boundary class -1 only: > 0 = Newton iterations this launch may spend on a reach (fs_batch_iterate)
+  int32_t *it_done;        // [B] with iter_budget: iterations already spent on the open level, -1 once the reach has closed it
   R theta, dt, dx, tol;
   R *hk, *Qk;              // [B][N] accepted state of the current level (in: level0, out: level0+n_steps)
   R *hg, *Qg;              // [B][N] Newton start vector for the next level
@@ -341,6 +345,14 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
   const int reach = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // One Newton iteration per launch for batches with host-evaluated boundary rows (FS_BC_HOST_ROW, fs_batch_iterate): the
+  // kernels of boundary class -1 carry an iteration budget and the count of the open level across launches.
+  constexpr bool kBudget = (BCK == -1);
+  int it_entry = 0;
+  if (kBudget && a.iter_budget > 0) {
+    it_entry = a.it_done[reach];
+    if (it_entry < 0) return;                 // this reach has closed the level: it waits for the others (whole workgroup)
+  }
   const int N = a.N, NC = N - 1;
   const int s0 = t * M;                       // first node / cell of this lane
   const int tD = (NC - 1) / M;                // lane that owns the last real cell
@@ -470,10 +482,12 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     const int level = a.level0 + step + 1;
     if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
     if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
-    int it = 0;
+    int it = kBudget ? it_entry : 0;
+    int budget = (kBudget && a.iter_budget > 0) ? a.iter_budget : 0x7fffffff;
     bool converged = false;
     R Ynew = Yprev;
     while (!converged && status == FS_OK) {
+      if (kBudget && budget-- <= 0) break;
       ++it;
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
       parity ^= 1;
@@ -680,7 +694,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       FS_T(4);
       const R err = sqrt_(tot);                                        // utility.py:20-22
       if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
-      if (!(err == err) || !(err <= R(1e300))) status = FS_NAN;
+      if (!(err == err) || !(err <= huge_norm<R>())) status = FS_NAN;        // NaN or overflow (preissmann.py:135-137)
       converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
       if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP)
         a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
@@ -844,6 +858,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       for (int j = 0; j <= M; ++j) { h[j] += dh[j]; Q[j] += dQ[j]; }     // preissmann.py:146-147
     }
     if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
+    if (kBudget && a.iter_budget > 0) {
+      if (t == 0) a.it_done[reach] = (converged || status != FS_OK) ? -1 : it;
+      if (!converged) break;                  // budget spent: the Newton vector goes back to hg / Qg below
+    }
   }
 
   // ---- Newton start vector of the next level + per-reach bookkeeping ----

@@ -18,7 +18,7 @@ GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_comp
             "b_fp_l", "b_fp_r", "m_fp", "curvature")
 GEO_NPARAM = len(GEO_ROWS)
 (BC_FLOW_HYDROGRAPH, BC_STAGE_HYDROGRAPH, BC_FIXED_DEPTH, BC_NORMAL_DEPTH, BC_RATING_POWER,
- BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE, BC_STORAGE_CURVE) = range(9)
+ BC_RATING_POLY, BC_RATING_BLEND, BC_STORAGE, BC_STORAGE_CURVE, BC_HOST_ROW) = range(10)
 # scalar slots of BC_STORAGE_CURVE (FS_SC_* of the header), followed by stage[n_curve], area[n_curve]
 SC_NAMES = ("min_stage", "Y_min", "Y_max", "bed_level", "surface_area", "alpha", "beta", "n_curve", "rc_type", "rc_a",
             "rc_b", "rc_c", "rc_shift", "capture_losses", "reservoir_length", "K_q")
@@ -26,7 +26,8 @@ UPSTREAM, DOWNSTREAM = 0, 1
 OK, MAX_ITER, NAN, STORAGE_RANGE = 0, 1, 2, 3
 FLAG_HISTORY, FLAG_TRACE = 1, 2
 TRACE_CAP = 64
-ABI_VERSION = 1
+DERIVE_ALL = 255
+ABI_VERSION = 2
 
 
 class BatchDesc(C.Structure):
@@ -55,6 +56,10 @@ SIGNATURES = {
     "fs_batch_set_state_uniform": (C.c_int, [_P, _D, _D]),
     "fs_batch_step": (C.c_int, [_P, C.c_int32]),
     "fs_batch_sync": (C.c_int, [_P]),
+    "fs_batch_iterate": (C.c_int, [_P, _I]),
+    "fs_batch_set_host_rows": (C.c_int, [_P, C.c_int32, _D]),
+    "fs_batch_get_boundary_iterate": (C.c_int, [_P, _D]),
+    "fs_batch_restart": (C.c_int, [_P, C.c_int32, _D, _D, _D, _D, _D]),
     "fs_batch_level": (C.c_int32, [_P]),
     "fs_batch_get_state": (C.c_int, [_P, _D, _D]),
     "fs_batch_get_guess": (C.c_int, [_P, _D, _D]),
@@ -66,11 +71,16 @@ SIGNATURES = {
     "fs_batch_get_storage_stage": (C.c_int, [_P, _D]),
     "fs_batch_get_storage_stages": (C.c_int, [_P, C.c_int32, C.c_int32, _D]),
     "fs_batch_derive": (C.c_int, [_P, C.c_int32, C.c_int32, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "fs_batch_derive_device": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    "fs_batch_derived_device_ptr": (_P, [_P, C.c_int32]),
     "fs_batch_hydrograph_device_ptr": (_P, [_P]),
     "fs_batch_stream": (_P, [_P]),
     "fs_batch_last_step_ms": (C.c_double, [_P]),
     "fs_batch_last_launch_count": (C.c_int32, [_P]),
     "fs_batch_kernel_info": (C.c_int, [_P, _I, _I, _I, _I]),
+    "fs_kernel_table_size": (C.c_int32, []),
+    "fs_kernel_table_entry": (C.c_int, [C.c_int32, _I]),
+    "fs_batch_kernel_index": (C.c_int32, [_P]),
 }
 
 _lib = None
@@ -110,3 +120,17 @@ def check(rc, what=""):
 
 def device_count():
     return lib().fs_device_count()
+
+
+KERNEL_FIELDS = ("dtype", "section_mode", "cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag", "pivoted")
+
+
+def kernel_table():
+    """The dispatch table of the step kernel: one dict per instantiation (fs_kernel_table_entry)."""
+    l = lib()
+    out = []
+    for i in range(l.fs_kernel_table_size()):
+        v = (C.c_int32 * 8)()
+        check(l.fs_kernel_table_entry(i, v), "kernel_table")
+        out.append(dict(zip(KERNEL_FIELDS, (int(x) for x in v)), index=i))
+    return out

@@ -117,6 +117,10 @@ class PreissmannBatch:
             _dptr(ov) if ov is not None else None), "set_geometry_irregular")
 
     def set_boundary(self, side: int, spec: BoundarySpec):
+        if spec.kind == A.BC_HOST_ROW:
+            # evaluated by the caller before every Newton iteration (set_host_rows / iterate)
+            A.check(self._lib.fs_batch_set_bc(self._h, side, spec.kind, None, 3, 1, None), "set_boundary")
+            return
         if spec.kind == A.BC_STORAGE_CURVE:
             # general LumpedStorage: the FS_SC_* scalars (missing ones default to 0, alpha to 1) + the area curve
             curve = np.asarray(spec.params.get("curve", np.empty((0, 2))), dtype=np.float64).reshape(-1, 2)
@@ -165,6 +169,33 @@ class PreissmannBatch:
 
     def sync(self):
         A.check(self._lib.fs_batch_sync(self._h), "sync")
+
+    def iterate(self) -> int:
+        """One Newton iteration of level `level + 1` for every reach still iterating on it; returns how many
+        remain open (0: the level is complete and `level` has advanced)."""
+        n = C.c_int32()
+        A.check(self._lib.fs_batch_iterate(self._h, C.byref(n)), "iterate")
+        return n.value
+
+    def set_host_rows(self, side: int, dh, dq, res):
+        """Boundary row (d/dh, d/dQ, residual) of every reach at the current Newton vector (BC_HOST_ROW sides)."""
+        rows = np.empty((3, self.B), dtype=np.float64)
+        rows[0], rows[1], rows[2] = dh, dq, res
+        A.check(self._lib.fs_batch_set_host_rows(self._h, side, _dptr(rows)), "set_host_rows")
+
+    def boundary_iterate(self):
+        """[4, B]: h[0], Q[0], h[N-1], Q[N-1] of the current Newton vector."""
+        out = np.empty((4, self.B))
+        A.check(self._lib.fs_batch_get_boundary_iterate(self._h, _dptr(out)), "get_boundary_iterate")
+        return out
+
+    def restart(self, level: int, h, Q, h_guess, Q_guess, storage_stage=None):
+        """Continue bit-exactly from `level`: state, Newton start vector of level + 1 and reservoir stage."""
+        arrs = [np.ascontiguousarray(np.broadcast_to(np.asarray(a, dtype=np.float64), (self.B, self.N)))
+                for a in (h, Q, h_guess, Q_guess)]
+        st = None if storage_stage is None else np.ascontiguousarray(np.broadcast_to(np.asarray(storage_stage, dtype=np.float64), (self.B,)))
+        A.check(self._lib.fs_batch_restart(self._h, int(level), *[_dptr(a) for a in arrs], _dptr(st) if st is not None else None),
+                "restart")
 
     @property
     def level(self):
@@ -248,6 +279,17 @@ class PreissmannBatch:
         v = [C.c_int32() for _ in range(4)]
         A.check(self._lib.fs_batch_kernel_info(self._h, *[C.byref(x) for x in v]), "kernel_info")
         return dict(cells_per_thread=v[0].value, waves_per_reach=v[1].value, lds_bytes=v[2].value, vgprs=v[3].value)
+
+    def kernel_index(self):
+        """index into _abi.kernel_table() of the instantiation the last step / iterate launched"""
+        return self._lib.fs_batch_kernel_index(self._h)
+
+    def derive_device(self, first=0, n=None, fields=A.DERIVE_ALL):
+        """prepare_results with the results left on the device; returns {name: device pointer}."""
+        n = self.level + 1 - first if n is None else n
+        A.check(self._lib.fs_batch_derive_device(self._h, first, n, int(fields)), "derive_device")
+        names = self.DERIVED + ("peak_amplitude",)
+        return {k: self._lib.fs_batch_derived_device_ptr(self._h, i) for i, k in enumerate(names) if fields & (1 << i)}
 
     def hydrograph_device_ptr(self):
         return self._lib.fs_batch_hydrograph_device_ptr(self._h)

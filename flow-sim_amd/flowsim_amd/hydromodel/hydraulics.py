@@ -22,6 +22,21 @@ def Sf(Q, K):
     return Q * np.abs(Q) / K ** 2
 
 
+def dK_dA(A, n, R, dR_dA):
+    """hydraulics.py:28-40"""
+    return (R ** (2 / 3) + A * 2. / 3. * R ** (2 / 3 - 1) * dR_dA) / n
+
+
+def dSf_dA(Q, K, dK_dA):
+    """hydraulics.py:59-75"""
+    return -2 * Sf(Q=Q, K=K) * (dK_dA / K)
+
+
+def dSf_dQ(Q, K):
+    """hydraulics.py:77-92"""
+    return 2 * abs(Q) / K ** 2
+
+
 def froude_num(T, A, Q):
     """Froude number with the reference's 1e-6 clamps (hydraulics.py:155-168)."""
     V = Q / max(A, 1e-6)

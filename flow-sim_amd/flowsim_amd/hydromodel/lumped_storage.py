@@ -59,9 +59,40 @@ class LumpedStorage:
         h_exp = 0 if A_str is None else (1 - entry_area / A_str) ** 2 * V ** 2 / (2 * hydraulics.g)
         return hf + h_exp + self.K_q * V ** 2 / (2 * hydraulics.g)
 
+    def dhl_dA(self, entry_area, flow, roughness, hydraulic_radius, dR_dA, A_str=None):
+        """d(head loss)/dA of the entry section (lumped_storage.py:76-113); expansion term as energy_loss"""
+        if not self.capture_losses:
+            return 0
+        from . import hydraulics
+        K = hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)
+        dhf = hydraulics.dSf_dA(Q=flow, K=K, dK_dA=hydraulics.dK_dA(A=entry_area, n=roughness, R=hydraulic_radius, dR_dA=dR_dA)) \
+            * self.reservoir_length
+        V, dV = flow / entry_area, -flow / entry_area ** 2
+        dexp = 0
+        if A_str is not None:
+            Kx = (1 - entry_area / A_str) ** 2
+            dexp = (Kx * 2 * V * dV + V ** 2 * 2 * (1 - entry_area / A_str) * (-1 / A_str)) / (2 * hydraulics.g)
+        return dhf + dexp + self.K_q * 2 * V * dV / (2 * hydraulics.g)
+
+    def dhl_dQ(self, entry_area, flow, roughness, hydraulic_radius, A_str=None):
+        """d(head loss)/dQ (lumped_storage.py:115-143; its expansion term differentiates V with -Q/A^2)"""
+        if not self.capture_losses:
+            return 0
+        from . import hydraulics
+        K = hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)
+        V = flow / entry_area
+        dexp = 0 if A_str is None else (1 - entry_area / A_str) ** 2 * 2 * V * (-flow / entry_area ** 2) / (2 * hydraulics.g)
+        return hydraulics.dSf_dQ(Q=flow, K=K) * self.reservoir_length + dexp + self.K_q * 2 * V * (1. / entry_area) / (2 * hydraulics.g)
+
+    def dY_new_dvol_in(self, duration, vol_in, Y_old, time=None) -> float:
+        """d(new stage)/d(inflow volume) = 1 / surface area, 0 on the min_stage floor (lumped_storage.py:37-45)"""
+        Y_new = self.mass_balance(duration, vol_in, Y_old, time)
+        return 0.0 if Y_new <= self.min_stage else 1 / self.area_at(Y_new)
+
     def mass_balance(self, duration, vol_in, Y_old=None, time=None):
-        """Stage after taking vol_in over `duration` (lumped_storage.py:24-35), host evaluation for
-        set-up and post-processing; the Newton loop uses the device form."""
+        """Stage after taking vol_in over `duration` (lumped_storage.py:24-35): host evaluation for set-up,
+        post-processing and for storages whose rating curve has no device form (Boundary.condition_residual);
+        otherwise the Newton loop uses the device form."""
         from scipy.optimize import brentq
 
         def f(Y_new):
@@ -85,9 +116,11 @@ class LumpedStorage:
             p.update(alpha=self.alpha, beta=self.beta, curve=self.area_curve)
         rc = self.rating_curve
         if rc is not None:
-            if getattr(rc, "function", None) is not None or rc.type not in ("power", "polynomial"):
-                raise NotImplementedError("the reservoir rating curve must be RatingCurve.set('power' | 'polynomial', ...) "
-                                          "to run inside the kernel")
+            from .rating_curve import RatingCurve
+            if (getattr(rc, "function", None) is not None or getattr(rc, "type", None) not in ("power", "polynomial")
+                    or type(rc).discharge is not RatingCurve.discharge):
+                raise NotImplementedError("only RatingCurve.set('power' | 'polynomial', ...) reservoir rating curves run inside the "
+                                          "kernel; this one is evaluated on the host (FS_BC_HOST_ROW)")
             p.update(rc_type=1.0 if rc.type == "power" else 2.0, rc_a=rc.a, rc_b=rc.b,
                      rc_c=getattr(rc, "c", 0.0) if rc.type == "polynomial" else 0.0, rc_shift=getattr(rc, "stage_shift", 0.0))
         if self.capture_losses:

@@ -19,8 +19,15 @@ _KIND = {"flow": A.BC_FLOW_HYDROGRAPH, "stage": A.BC_STAGE_HYDROGRAPH, "fixed": 
          "blend": A.BC_RATING_BLEND, "storage": A.BC_STORAGE, "storage_curve": A.BC_STORAGE_CURVE}
 
 
-def boundary_to_spec(boundary, n_levels, dt) -> BoundarySpec:
-    kind, params, target = boundary.device_spec(n_levels, dt)
+def boundary_to_spec(boundary, n_levels, dt, host_fallback=False) -> BoundarySpec:
+    """Device form of a boundary; with host_fallback a plugin without one (NotImplementedError from its
+    device_spec) becomes an FS_BC_HOST_ROW boundary instead, evaluated in Python every Newton iteration."""
+    try:
+        kind, params, target = boundary.device_spec(n_levels, dt)
+    except NotImplementedError:
+        if not host_fallback:
+            raise
+        return BoundarySpec(A.BC_HOST_ROW)
     return BoundarySpec(_KIND[kind], params, target)
 
 
@@ -44,10 +51,11 @@ class PreissmannSolver(Solver):
         rect = ("irr_npts" not in geo and np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)
                 and np.ptp(geo["b_main"]) == 0 and np.ptp(geo["n_main"]) == 0 and ch.input_xs is not None
                 and len(ch.input_xs) == 2)
-        us_spec = boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step)
-        ds_spec = boundary_to_spec(ch.downstream_boundary, max(nt, 2), self.time_step)
-        # the general reservoir row is compiled into the table / polyline kernels only
-        rect = rect and A.BC_STORAGE_CURVE not in (us_spec.kind, ds_spec.kind)
+        us_spec = boundary_to_spec(ch.upstream_boundary, max(nt, 2), self.time_step, host_fallback=True)
+        ds_spec = boundary_to_spec(ch.downstream_boundary, max(nt, 2), self.time_step, host_fallback=True)
+        host_sides = [side for side, sp in ((A.UPSTREAM, us_spec), (A.DOWNSTREAM, ds_spec)) if sp.kind == A.BC_HOST_ROW]
+        # the general reservoir row and host-evaluated rows are compiled into the table / polyline kernels only
+        rect = rect and A.BC_STORAGE_CURVE not in (us_spec.kind, ds_spec.kind) and not host_sides
         poly = "irr_npts" in geo                   # any IrregularSection node (cross_section.py:207-543)
         mode = "irregular" if poly else ("rect_uniform" if rect else "table")
         with PreissmannBatch(1, N, max(nt, 2), dtype=dtype, section_mode=mode, history=True, trace=(verbose == 3)) as b:
@@ -61,7 +69,9 @@ class PreissmannSolver(Solver):
             b.set_boundary(A.UPSTREAM, us_spec)
             b.set_boundary(A.DOWNSTREAM, ds_spec)
             b.set_state(ch.initial_conditions[:, 0], ch.initial_conditions[:, 1])
-            if nt > 1:
+            if nt > 1 and host_sides:
+                self._run_with_host_rows(b, host_sides, nt)
+            elif nt > 1:
                 b.step(nt - 1)
             status = int(b.status()[0])
             its = b.iterations(0, max(nt, 2))[:nt, 0]
@@ -89,7 +99,7 @@ class PreissmannSolver(Solver):
         self.time_level = nt - 1
         self.depth[:], self.flow[:] = h[:nt, 0], Q[:nt, 0]
         st = ch.downstream_boundary.lumped_storage
-        if st is not None:
+        if st is not None and A.DOWNSTREAM not in host_sides:     # (a host-evaluated storage keeps the list itself)
             st.stage_hydrograph = [[k * self.time_step, float(stages[k])] for k in range(1, nt)]
         if verbose >= 1:      # same lines as the reference prints while it runs (preissmann.py:116-159)
             for k in range(1, nt):
@@ -100,6 +110,35 @@ class PreissmannSolver(Solver):
                 if verbose == 2:
                     print(f'>> {its[k]} iterations.')
         self._finalize(verbose)
+
+    def _run_with_host_rows(self, b, host_sides, nt) -> None:
+        """The Newton loop with boundary plugins that have no device form (any object honouring discharge(stage, time) /
+        dQ_dz, a LumpedStorage with a callable rating curve): one kernel launch per Newton iteration, the rows of those
+        boundaries evaluated here in between, in the reference's order - both residuals (preissmann.py:76-77), then the
+        upstream and the downstream derivatives (:322-344) - because a plugin may carry state from call to call."""
+        ch, dt = self.channel, self.time_step
+        ends = {A.UPSTREAM: (ch.upstream_boundary, 0, 1), A.DOWNSTREAM: (ch.downstream_boundary, 2, 3)}
+        for k in range(1, nt):
+            t = k * dt
+            Q_old = b.hydrographs(k - 1, 1)[0, :, 0]            # flow[k-1] at the two ends (vol_in, preissmann.py:314)
+            while True:
+                it = b.boundary_iterate()[:, 0]
+                res, rows = {}, {}
+                for side in sorted(host_sides):
+                    bnd, ih, iq = ends[side]
+                    vol = 0.5 * (it[iq] + Q_old[iq]) * dt
+                    res[side] = bnd.condition_residual(depth=it[ih], flow=it[iq], time=t, duration=dt, vol_in=vol)
+                for side in sorted(host_sides):
+                    bnd, ih, iq = ends[side]
+                    vol = 0.5 * (it[iq] + Q_old[iq]) * dt
+                    rows[side] = (bnd.df_dh(depth=it[ih], flow_rate=it[iq], time=t),
+                                  bnd.df_dQ(depth=it[ih], flow_rate=it[iq], duration=dt, time=t, vol_in=vol))
+                for side in host_sides:
+                    b.set_host_rows(side, rows[side][0], rows[side][1], res[side])
+                if b.iterate() == 0:
+                    break
+            if int(b.status()[0]) != A.OK:
+                return
 
     def check_criticality(self) -> None:
         """Froude diagnosis printed before a convergence failure is raised (preissmann.py:179-198)."""

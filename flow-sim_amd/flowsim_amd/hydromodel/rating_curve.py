@@ -1,10 +1,11 @@
 """RatingCurve: stage-discharge relation Q(stage) as power law or quadratic
 (reference: src/hydromodel/rating_curve.py:4-162).
 
-Plugin contract for the device path: `device_spec()` returns (kind, params) understood by the
-C ABI (FS_BC_RATING_POWER / _POLY / _BLEND).  A subclass with its own Python `discharge` must
-override device_spec() (see cases/gerd_roseires) - an arbitrary Python callable cannot run inside
-the kernel."""
+Plugin contract: `device_spec()` returns (kind, params) understood by the C ABI (FS_BC_RATING_POWER /
+_POLY / _BLEND) and the boundary row is then evaluated inside the kernel.  A subclass with its own Python
+`discharge` either overrides device_spec() (cases/gerd_roseires, smooth gates) or lets it raise
+NotImplementedError: PreissmannSolver.run then evaluates that boundary on the host once per Newton
+iteration (FS_BC_HOST_ROW) - any object with discharge(stage, time) / dQ_dz(stage, time) runs."""
 import numpy as np
 
 
@@ -106,14 +107,21 @@ class RatingCurve:
         self._need()
         if type(self).discharge is not RatingCurve.discharge or type(self).dQ_dz is not RatingCurve.dQ_dz:
             raise NotImplementedError(
-                f"{type(self).__name__} overrides discharge()/dQ_dz() in Python; give it a device_spec() "
-                "(power, polynomial or smooth blend of two quadratics) so it can run inside the kernel")
+                f"{type(self).__name__} overrides discharge()/dQ_dz() in Python and has no device_spec() "
+                "(power, polynomial or smooth blend of two quadratics): evaluated on the host (FS_BC_HOST_ROW)")
         if self.function is not None:
-            coef = self.function.convert().coef          # fitted, scaled polynomial -> plain a x^2 + b x + c
-            c = list(coef) + [0.0] * (3 - len(coef))
+            # fit(..., scale=True): discharge() evaluates the fitted polynomial at the STAGE, dQ_dz() its derivative at
+            # stage + stage_shift (rating_curve.py:51-52, :139-141).  The device row uses one abscissa for both, so only a
+            # fit without shift has a device form; any other callable (or a shifted fit) is evaluated on the host.
+            poly = self.function
+            if not isinstance(poly, np.polynomial.Polynomial) or self.stage_shift != 0:
+                raise NotImplementedError("a rating curve given as a Python callable (or a scaled fit with a stage shift) "
+                                          "has no device form: evaluated on the host (FS_BC_HOST_ROW)")
+            coef = poly.convert().coef          # fitted, scaled polynomial -> plain a x^2 + b x + c
             if len(coef) > 3:
-                raise NotImplementedError("fitted rating polynomials above degree 2 have no device form")
-            return "poly", dict(a=c[2], b=c[1], c=c[0], stage_shift=self.stage_shift, bed_level=bed_level)
+                raise NotImplementedError("fitted rating polynomials above degree 2 have no device form: evaluated on the host")
+            c = list(coef) + [0.0] * (3 - len(coef))
+            return "poly", dict(a=c[2], b=c[1], c=c[0], stage_shift=0.0, bed_level=bed_level)
         if self.type == 'polynomial':
             return "poly", dict(a=self.a, b=self.b, c=self.c, stage_shift=self.stage_shift, bed_level=bed_level)
         return "power", dict(a=self.a, b=self.b, stage_shift=self.stage_shift, bed_level=bed_level)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 1
+#define FS_ABI_VERSION 2
 
 typedef struct fs_batch fs_batch;
 
@@ -79,7 +79,7 @@ enum {
   FS_BC_RATING_BLEND = 6,     /* params: stage0, buffer, lo0, lo1, lo2, hi0, hi1, hi2, dY, bed_level
                                  Q = (1-s)*lo(z) + s*hi(z), lo/hi quadratics in z, s = smoothstep */
   FS_BC_STORAGE = 7,          /* params: surface_area, min_stage, Y_min, Y_max, bed_level (downstream only) */
-  FS_BC_STORAGE_CURVE = 8     /* general LumpedStorage (lumped_storage.py:8-179; downstream only): area curve,
+  FS_BC_STORAGE_CURVE = 8,    /* general LumpedStorage (lumped_storage.py:8-179; downstream only): area curve,
                                  reservoir rating curve, entrance losses.  params[FS_SC_NFIXED + 2*n_curve]:
                                  the FS_SC_* scalars, then stage[n_curve], area[n_curve] of set_area_curve
                                  (n_curve = 0: constant surface_area).  The mass-balance root
@@ -87,6 +87,14 @@ enum {
                                  scipy.optimize.brentq and its default tolerances.  Section modes
                                  FS_SEC_TABLE and FS_SEC_IRREGULAR only (fs_batch_step refuses it in the
                                  uniform-geometry modes: describe such a channel as a table). */
+  FS_BC_HOST_ROW = 9          /* a boundary whose plugin has no device form: any object with discharge(stage, time) /
+                                 dQ_dz(stage, time) (rating_curve.py:32-63,:132-147; e.g. RoseiresRatingCurve(smooth=False),
+                                 cases/gerd_roseires/roseires_rating_curve.py:65-140, whose gates move with time) or a
+                                 LumpedStorage with a callable rating curve (lumped_storage.py:24-35).  params[3][B]
+                                 (per_reach = 1) = (d/dh, d/dQ, residual) of the boundary equation at the current Newton
+                                 vector, evaluated by the caller before every iteration (boundary.py:56-242) and handed over
+                                 with fs_batch_set_host_rows; such a batch advances with fs_batch_iterate (one Newton
+                                 iteration per launch), not fs_batch_step.  Section modes FS_SEC_TABLE / FS_SEC_IRREGULAR. */
 };
 /* scalar slots of FS_BC_STORAGE_CURVE */
 enum {
@@ -170,6 +178,27 @@ int fs_batch_step(fs_batch *b, int32_t n_steps);
 int fs_batch_sync(fs_batch *b);
 int32_t fs_batch_level(const fs_batch *b);   /* current time level k */
 
+/* The same loop opened up for boundaries evaluated on the host (FS_BC_HOST_ROW): ONE Newton iteration
+ * (preissmann.py:122-156: residual, Jacobian, solve, update, norm test) of level fs_batch_level() + 1 for every reach
+ * that has not converged on it yet.  *n_open (may be NULL) returns how many reaches still iterate; when it reaches 0
+ * the level is complete for the whole batch and fs_batch_level() has advanced.  Synchronous.  Works for any TABLE /
+ * IRREGULAR batch (device-evaluated kinds included). */
+int fs_batch_iterate(fs_batch *b, int32_t *n_open);
+/* rows[3][B] = (d/dh, d/dQ, residual) of the side's boundary equation at the current Newton vector
+ * (Boundary.df_dh, df_dQ, condition_residual: boundary.py:143-242, :56-141) */
+int fs_batch_set_host_rows(fs_batch *b, int32_t side, const double *rows);
+/* the current Newton vector at the two boundary nodes, out[4][B] = h[0], Q[0], h[N-1], Q[N-1]
+ * (what preissmann.py:200-218, :303-320 pass to the boundary: depth_at / flow_at of the iterate) */
+int fs_batch_get_boundary_iterate(fs_batch *b, double *out);
+
+/* Restart (the reference keeps its whole history in memory and has no restart, solver.py:43-44):
+ * everything a run needs to continue bit-exactly from time level `level`: depth/flow[level] (h, Q: what
+ * fs_batch_get_state returned), the Newton start vector of level+1 (h_guess, Q_guess: fs_batch_get_guess; after the
+ * first level it differs from the state) and, behind a storage boundary, the reservoir stage of `level`
+ * (storage_stage[B]: fs_batch_get_storage_stage; NULL otherwise).  All [B][N] float64. */
+int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *Q, const double *h_guess,
+                     const double *Q_guess, const double *storage_stage);
+
 /* depth[k], flow[k] of the current level (what update_guesses stored, preissmann.py:166-177).
  * The kernel writes the accepted state to HBM at the last level of each fs_batch_step call (and at
  * every level into the history when FS_FLAG_HISTORY is set); for a reach whose status is not FS_OK
@@ -197,10 +226,18 @@ int fs_batch_get_storage_stages(fs_batch *b, int32_t first_level, int32_t n_leve
  * (FS_FLAG_HISTORY): level = depth + bed, area, top width, Froude number (hydraulics.py:155-168),
  * velocity Q/A, wave celerity V + sqrt(g A / T), amplitude = depth - depth[0]; each [n][B][N], and
  * peak_amplitude [B][N] = max over those levels.  Any output pointer may be NULL.  One elementwise,
- * HBM-bound kernel; results are copied to the caller's host arrays. */
+ * HBM-bound kernel; results are copied to the caller's host arrays (the device buffers behind them are
+ * kept by the handle and reused by later calls). */
 int fs_batch_derive(fs_batch *b, int32_t first_level, int32_t n_levels, double *level, double *area,
                     double *top_width, double *froude, double *velocity, double *celerity,
                     double *amplitude, double *peak_amplitude);
+/* The same kernel with the results left on the device (no PCIe traffic): fields = bit mask of FS_DERIVE_* to
+ * compute; fs_batch_derived_device_ptr(field index 0..7) then points at [n_levels][B][N] (index 7,
+ * peak amplitude: [B][N]) in the batch dtype, valid until the next derive call on this handle. */
+enum { FS_DERIVE_LEVEL = 1, FS_DERIVE_AREA = 2, FS_DERIVE_TOP_WIDTH = 4, FS_DERIVE_FROUDE = 8, FS_DERIVE_VELOCITY = 16,
+       FS_DERIVE_CELERITY = 32, FS_DERIVE_AMPLITUDE = 64, FS_DERIVE_PEAK_AMPLITUDE = 128, FS_DERIVE_ALL = 255 };
+int fs_batch_derive_device(fs_batch *b, int32_t first_level, int32_t n_levels, int32_t fields);
+void *fs_batch_derived_device_ptr(fs_batch *b, int32_t field_index);
 
 /* zero-copy access for device-side consumers (RCCL gather of hydrographs): device pointer to the
  * [max_levels][4][B] hydrograph block in the batch dtype, and the handle's hipStream_t */
@@ -213,6 +250,16 @@ double fs_batch_last_step_ms(fs_batch *b);
 int32_t fs_batch_last_launch_count(fs_batch *b);
 int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach,
                          int32_t *lds_bytes, int32_t *vgprs);
+/* The dispatch table of the step kernel (what fs_batch_step chooses from): fs_kernel_table_size() entries,
+ * entry i described by out[8] = dtype, section_mode, cells per lane M, waves per reach W, full (1: only
+ * N-1 in {64*W*M-1, 64*W*M}), boundary class (-1 any kind, 0 any but FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW,
+ * 1 closed-form rectangular rows, 2+k flow hydrograph upstream and kind k downstream), diag (0: compiled
+ * without history / trace stores), pivoted (1: the re-solve kernels with 2x2 pivot choice).  The environment
+ * variable FS_KERNEL_INDEX=i makes fs_batch_step use entry i or fail if it does not fit the batch (tests:
+ * every instantiation is checked against the oracle). fs_batch_kernel_index: the entry the last step used. */
+int32_t fs_kernel_table_size(void);
+int fs_kernel_table_entry(int32_t i, int32_t *out);
+int32_t fs_batch_kernel_index(fs_batch *b);
 
 #ifdef __cplusplus
 }

@@ -99,8 +99,10 @@ def section_soa(channel):
     return out
 
 
-def run_and_capture(solver, tolerance, max_iter=100):
-    """Calls the reference's own PreissmannSolver.run (preissmann.py:101-163)."""
+def run_and_capture(solver, tolerance, max_iter=100, slim=False):
+    """Calls the reference's own PreissmannSolver.run (preissmann.py:101-163).  slim: benchmark-size fixtures keep
+    geometry, initial conditions, the solution, the Newton counts / norms and the first residual vector only (no
+    Jacobian entries, no derived fields)."""
     solver.prepare_results = lambda: None          # post-processing is not on the hot path
     ic = np.array(solver.channel.initial_conditions, dtype=np.float64)
     t0 = time.time()
@@ -122,6 +124,9 @@ def run_and_capture(solver, tolerance, max_iter=100):
         final_unknowns=np.array(solver.unknowns, dtype=np.float64),
     )
     out.update({"geo_" + k: v for k, v in section_soa(solver.channel).items()})
+    if slim:
+        del out["J0"], out["delta0"]
+        return out, wall
     # post-processing of the reference (Solver.prepare_results, solver.py:65-127) on the stored solution
     from src.hydromodel.solver import Solver
     Solver.prepare_results(solver)
@@ -236,7 +241,7 @@ def case_example():
                                    storage_bounds=[0, 200], ds_initial_depth=5.0))
 
 
-def synthetic_rect(name, B, N, n_steps, seed, theta=0.6, dt=600, dx=250.0, tol=1e-6):
+def synthetic_rect(name, B, N, n_steps, seed, theta=0.6, dt=600, dx=250.0, tol=1e-6, slim=False):
     """SURVEY 8(d) C3 generator at a small shape, built through the reference's public API
     (Channel(width=, roughness=) -> provisional rectangular sections, channel.py:282-294)."""
     from src.hydromodel.channel import Channel
@@ -258,7 +263,7 @@ def synthetic_rect(name, B, N, n_steps, seed, theta=0.6, dt=600, dx=250.0, tol=1
                      downstream_boundary=ds, interpolation_method='steady-state')
         sol = PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx,
                                simulation_time=n_steps * dt)
-        out, wall = run_and_capture(sol, tol)
+        out, wall = run_and_capture(sol, tol, slim=slim)
         out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
         params.append([b, n, S0, Qb])
         for k, v in out.items():
@@ -275,7 +280,7 @@ def synthetic_rect(name, B, N, n_steps, seed, theta=0.6, dt=600, dx=250.0, tol=1
     save(name, arrays, meta)
 
 
-def synthetic_trap(name, B, N, n_steps, seed, theta=0.6, dt=1800, dx=500.0, tol=1e-6):
+def synthetic_trap(name, B, N, n_steps, seed, theta=0.6, dt=1800, dx=500.0, tol=1e-6, slim=False):
     """SURVEY 8(d) C5 generator at a small shape in fp64: simple trapezoid + power rating curve."""
     from src.hydromodel.channel import Channel
     from src.hydromodel.boundary import Boundary
@@ -304,7 +309,7 @@ def synthetic_trap(name, B, N, n_steps, seed, theta=0.6, dt=1800, dx=500.0, tol=
         ch.set_cross_sections([0.0, L], [xs_u, xs_d])
         sol = PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx,
                                simulation_time=n_steps * dt)
-        out, wall = run_and_capture(sol, tol)
+        out, wall = run_and_capture(sol, tol, slim=slim)
         out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
         params.append([b, m, n, S0, Qb, h_n, a, be])
         for k, v in out.items():
@@ -651,6 +656,312 @@ def case_gerd(steps):
     os.chdir(os.path.dirname(os.path.abspath(__file__)))
 
 
+def case_upstream_kinds():
+    """The three boundary kinds the other fixtures only ever have downstream, imposed upstream (boundary.py:56-242 serves
+    both ends; preissmann.py:200-218, :346-400 call it for node 0), and a flow hydrograph imposed downstream."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.rating_curve import RatingCurve
+    from src.hydromodel.cross_section import TrapezoidalSection
+
+    # (a) reservoir level upstream (fixed_depth), gate closing downstream (outflow hydrograph that dips)
+    L = 10000.0; S0 = 2e-4; Q0 = 150.0
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=40.0, m_main=1.5, n_main=0.03, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=0.0, b_main=40.0, m_main=1.5, n_main=0.03, bed_slope=S0)
+    hn = xs_d.normal_depth(Q_target=Q0)
+    hyd = Hydrograph(akbari_hydrograph(Q0, -60.0, 2 * 3600.0, 6 * 3600.0))
+    us = Boundary(condition='fixed_depth', bed_level=S0 * L, chainage=0, initial_depth=hn)
+    ds = Boundary(condition='flow_hydrograph', bed_level=0.0, chainage=L, hydrograph=hyd, initial_depth=hn)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    sol = PreissmannSolver(channel=ch, theta=0.65, time_step=600, spatial_step=500, simulation_time=8 * 3600)
+    out, wall = run_and_capture(sol, 1e-6)
+    out["ds_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+    save("bc_us_fixed_ds_flow", out, base_meta(sol, 1e-6, wall, us_initial_depth=float(hn), ds_initial_depth=float(hn)))
+
+    # (b) head-dependent inflow upstream (rating curve with negative slope: Q falls as the stage rises), tide-like stage
+    #     hydrograph downstream, rectangular channel, linear IC
+    L = 8000.0; S0 = 3e-4; Q0 = 200.0; h_us = 3.0
+    rc = RatingCurve(); rc.set(type='polynomial', a=0.0, b=-60.0, c=Q0 + 60.0 * (S0 * L + h_us))
+    tab = np.array([[0, 3.0], [3600 * 2, 3.8], [3600 * 5, 3.2], [3600 * 12, 3.0]])
+    hyd = Hydrograph(table=tab)
+    us = Boundary(condition='rating_curve', bed_level=S0 * L, chainage=0, initial_depth=h_us, rating_curve=rc)
+    ds = Boundary(condition='stage_hydrograph', bed_level=0.0, chainage=L, initial_depth=3.0, hydrograph=hyd)
+    ch = Channel(width=60, initial_flow=Q0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds,
+                 interpolation_method='linear')
+    sol = PreissmannSolver(channel=ch, theta=0.7, time_step=900, spatial_step=500, simulation_time=8 * 3600)
+    out, wall = run_and_capture(sol, 1e-6)
+    out["ds_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+    save("bc_us_rating_ds_stage", out, base_meta(sol, 1e-6, wall, us_initial_depth=h_us, ds_initial_depth=3.0, width=60,
+                                                 roughness=0.03, us_rc_type='polynomial', us_rc_a=0.0, us_rc_b=-60.0,
+                                                 us_rc_c=float(rc.c), us_rc_shift=0.0))
+
+    # (c) normal depth imposed upstream, stage hydrograph downstream, simple trapezoid
+    L = 12000.0; S0 = 4e-4; Q0 = 180.0
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=50.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=0.0, b_main=50.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    hn = xs_d.normal_depth(Q_target=Q0)
+    tab = np.array([[0, hn], [3600 * 2, hn + 0.6], [3600 * 5, hn + 0.1], [3600 * 12, hn]])
+    hyd = Hydrograph(table=tab)
+    us = Boundary(condition='normal_depth', bed_level=S0 * L, chainage=0, initial_depth=hn)
+    ds = Boundary(condition='stage_hydrograph', bed_level=0.0, chainage=L, initial_depth=hn, hydrograph=hyd)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    sol = PreissmannSolver(channel=ch, theta=0.7, time_step=600, spatial_step=500, simulation_time=6 * 3600)
+    out, wall = run_and_capture(sol, 1e-6)
+    out["ds_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+    save("bc_us_normal_ds_stage", out, base_meta(sol, 1e-6, wall, us_initial_depth=float(hn), ds_initial_depth=float(hn)))
+
+
+def case_irr_storage():
+    """Polyline sections in front of a general LumpedStorage (area curve, polynomial outflow curve, entrance losses): the
+    boundary row then needs the polyline's A, R, n_eq, dR/dA, dA/dh at two stages (boundary.py:110-124, :152-164)."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.lumped_storage import LumpedStorage
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.rating_curve import RatingCurve
+    from src.hydromodel.cross_section import IrregularSection
+    L = 6000.0; S0 = 2e-4
+    xu = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); zu = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
+    xd = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zd = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
+    xs_u = IrregularSection(x=xu, z=S0 * L + zu, n=0.03, bed_slope=S0)
+    xs_d = IrregularSection(x=xd, z=zd, n=0.034, bed_slope=S0)
+    Qb = 40.0
+    hyd = Hydrograph(akbari_hydrograph(Qb, 260.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=2.2, bed_level=0.0, chainage=L)
+    stages = np.arange(0.0, 12.01, 0.25)
+    curve = np.column_stack([stages, 6.0e4 + 1.5e4 * stages + 500.0 * stages ** 2])
+    rc = RatingCurve(); rc.set(type='polynomial', a=4.0, b=6.0, c=0.0)
+    ss = LumpedStorage(surface_area=None, min_stage=1.0, solution_boundaries=(0, 12), rating_curve=rc)
+    ss.set_area_curve(curve, alpha=1.0, beta=0.0)
+    ss.capture_losses = True; ss.reservoir_length = 300.0; ss.K_q = 0.2
+    ds.set_lumped_storage(ss)
+    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds)
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    sol = PreissmannSolver(channel=ch, theta=0.7, time_step=300, spatial_step=500, simulation_time=3 * 3600)
+    out, wall = run_and_capture(sol, 1e-6)
+    out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+    out["storage_stage"] = np.array(ss.stage_hydrograph, dtype=np.float64)[1:]
+    save("irr_storage", out, base_meta(sol, 1e-6, wall, storage_curve=curve.tolist(), storage_alpha=1.0, storage_beta=0.0,
+                                       storage_min_stage=1.0, ds_initial_depth=2.2, storage_rc_type='polynomial',
+                                       storage_rc=dict(a=4.0, b=6.0, c=0.0, shift=0.0),
+                                       storage_losses=dict(reservoir_length=300.0, K_q=0.2),
+                                       storage_bounds=[float(ss.Y_min), float(ss.Y_max)]))
+
+
+def case_bench_size():
+    """The shapes bench.py launches, pinned to the reference itself: SURVEY 8(d) C3 draws at N = 4096 (two reaches, three
+    levels: 0.64 s per Newton iteration in the reference) and C5 draws at N = 512 (two reaches, five levels)."""
+    synthetic_rect("c3_4096", 2, 4096, 3, 20260213, slim=True)
+    synthetic_trap("c5_512", 2, 512, 5, 20260214, slim=True)
+
+
+def case_gerd_full():
+    """cases/gerd_roseires over its whole simulation (384 levels, settings.py:3-8), solution + Newton counts only."""
+    gd, cf, rr = _gerd_imports()
+    from cases.gerd_roseires import settings as S
+    sol, rel, rc, chs, secs = build_gerd(gd, cf, rr, None, S.sim_duration // 3600,
+                                         "cases/gerd_roseires/data/inflow_hydrograph.csv", True)
+    out, wall = run_and_capture(sol, S.tolerance, slim=True)
+    out["us_target"] = np.array(rel.table[:sol.number_of_time_levels, 1], dtype=np.float64)
+    save("gerd_full", out, base_meta(sol, S.tolerance, wall, rating=rating_spec(rc, rr),
+                                     ds_initial_depth=float(sol.channel.downstream_boundary.initial_depth)))
+    os.chdir(os.path.dirname(os.path.abspath(__file__)))
+
+
+GATES_INFLOW_SCALE, GATES_STEPS = 8.0, 40
+
+
+def case_gerd_gates():
+    """A boundary plugin with NO device form: RoseiresRatingCurve(smooth=False) (roseires_rating_curve.py:65-78, :111-140) -
+    the gates open / close on the stage of the previous evaluation with a cool-down in simulation time, so discharge() is
+    stateful and time-dependent.  The flood wave is the case's inflow table scaled by 8 above its base flow so that the
+    opening threshold (initial stage + 0.5 m) is crossed within 40 levels (gates open at level 27, close at level 36)."""
+    gd, cf, rr = _gerd_imports()
+    from cases.gerd_roseires import settings as S
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.preissmann import PreissmannSolver
+    tab = cf.import_hydrograph("cases/gerd_roseires/data/inflow_hydrograph.csv")
+    tab[:, 1] = tab[0, 1] + GATES_INFLOW_SCALE * (tab[:, 1] - tab[0, 1])
+    inflow = Hydrograph(table=tab)
+    rel = gd.GerdHydrograph()
+    rel.build(inflow_hydrograph=inflow, time_step=S.time_step, duration=GATES_STEPS * 3600, initial_stage=S.initial_gerd_level)
+    Q0 = rel.get_at(time=0)
+    chs, secs = cf.load_trapzoid_xs(file_path=S.cross_sections_path, n_fp=None, n_main=None)
+    bed = secs[-1].z_min
+    us = Boundary(condition='flow_hydrograph', hydrograph=rel, chainage=chs[0])
+    rc = rr.RoseiresRatingCurve(initial_stage=S.initial_roseires_level, initial_flow=Q0, smooth=False)
+    ds = Boundary(initial_depth=S.initial_roseires_level - bed, bed_level=bed, condition='rating_curve', rating_curve=rc,
+                  chainage=chs[-1])
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds)
+    c = cf.import_table(S.coords_path, sort_by='chainage')
+    ch.set_coords(coords=c[:, 1:], chainages=c[:, 0])
+    ch.set_cross_sections(chainages=chs, sections=secs)
+    sol = PreissmannSolver(channel=ch, theta=S.theta, time_step=S.time_step, spatial_step=S.spatial_step,
+                           simulation_time=GATES_STEPS * 3600)
+    out, wall = run_and_capture(sol, S.tolerance, slim=True)
+    out["us_target"] = np.array(rel.table[:sol.number_of_time_levels, 1], dtype=np.float64)
+    spec = rating_spec(rc, rr)
+    spec.update(smooth=False, max_cooldown=float(rc.max_cooldown))
+    save("gerd_gates", out, base_meta(sol, S.tolerance, wall, rating=spec, inflow_scale=GATES_INFLOW_SCALE,
+                                      ds_initial_depth=float(ds.initial_depth), host_evaluated="downstream"))
+    os.chdir(os.path.dirname(os.path.abspath(__file__)))
+
+
+def weir_outflow(stage):
+    """reservoir outlet of case_storage_callable: nothing below the crest, a broad-crested weir above it - a Python
+    callable handed to RatingCurve.function (rating_curve.py:50-52), which has no device form"""
+    crest = 6.0
+    return 0.0 if stage <= crest else 55.0 * (stage - crest) ** 1.5
+
+
+def case_storage_callable():
+    """LumpedStorage whose outflow rating curve is a Python callable (lumped_storage.py:24-35 calls
+    rating_curve.discharge(Y, time) inside the brentq root function): the second plugin shape without a device form."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.lumped_storage import LumpedStorage
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.rating_curve import RatingCurve
+    L = 10000.0; Qb = 200.0
+    hyd = Hydrograph(akbari_hydrograph(Qb, 900.0, 3 * 3600.0, 9 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=2.0, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=5, bed_level=0, chainage=L)
+    rc = RatingCurve(); rc.function = weir_outflow; rc.defined = True
+    ss = LumpedStorage(surface_area=8.0e5, min_stage=4.0, solution_boundaries=(0, 30), rating_curve=rc)
+    ds.set_lumped_storage(ss)
+    ch = Channel(width=100, initial_flow=Qb, roughness=0.03, upstream_boundary=us, downstream_boundary=ds)
+    sol = PreissmannSolver(channel=ch, theta=0.7, time_step=1200, spatial_step=500, simulation_time=12 * 3600)
+    out, wall = run_and_capture(sol, 1e-6)
+    out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+    out["storage_stage"] = np.array(ss.stage_hydrograph, dtype=np.float64)[1:]
+    save("storage_callable_rc", out, base_meta(sol, 1e-6, wall, storage_area=8.0e5, storage_min_stage=4.0,
+                                               storage_bounds=[0, 30], ds_initial_depth=5.0, width=100, roughness=0.03,
+                                               weir=dict(crest=6.0, coefficient=55.0, exponent=1.5),
+                                               host_evaluated="downstream"))
+
+
+def case_rmse_curve():
+    """the calibration loop of cases/gerd_roseires/n_calibrate.py:5-17, :55-67 - ten Manning-n values,
+    each a 32-level run of model.run on the small inflow table, GERD tail-water levels interpolated at six discharges,
+    RMSE against the target levels.  n_calibrate.py runs at import time and writes a CSV into the working directory, so its
+    two small functions (run_model, calc_rmse_curve) are called through model.run here with its module constants."""
+    _gerd_imports()
+    import cases.gerd_roseires.model as M
+    H_target = np.array([497.5, 500, 502, 505, 507, 510])          # n_calibrate.py:26-28
+    Q = np.array([1562.5, 3850, 6000, 10000, 14000, 21000])
+    n_values = np.linspace(0.020, 0.060, 10)                      # n_calibrate.py:66
+    Y, rmse = [], []
+    for n in n_values:
+        t0 = time.time()
+        y = np.array(M.run(n_main=float(n), Q=Q, verbose=0, folder=None,
+                           inflow_hyd_path="cases\\gerd_roseires\\data\\inflow_hydrograph_small.csv", coords_path=None,
+                           inflow_hyd_func=None, sim_duration=None))
+        Y.append(y)
+        rmse.append(float(np.mean((y - H_target) ** 2) ** 0.5))    # n_calibrate.py:60
+        print(f"   n_main={n:.5f}: RMSE {rmse[-1]:.6f}  ({time.time() - t0:.1f} s)")
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "rmse_curve.npz"),
+                        meta=np.array(json.dumps(dict(generator="oracle/gen_golden.py", kind="rmse_curve",
+                                                      reference="cve-mohd/flow-sim snapshot 2026-02-13, run in the build container"))),
+                        n_values=n_values, rmse=np.array(rmse), levels=np.array(Y), H_target=H_target, Q=Q)
+    os.chdir(os.path.dirname(os.path.abspath(__file__)))
+
+
+def case_result_summaries():
+    """Solver.save_results' text summary (solver.py:188-233) as the reference writes it, for cases/akbari_firoozi and
+    cases/example.  openpyxl is absent here, so pandas.ExcelWriter / DataFrame.to_excel are no-ops for the duration of the
+    call (harness side only): the workbook is not produced, the .txt next to it is the reference's own output."""
+    import tempfile
+    import pandas as pd
+    from src.hydromodel.solver import Solver
+
+    class NoWorkbook:
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *exc): return False
+
+    def summary(sol):
+        Solver.prepare_results(sol)
+        real_writer, real_to_excel = pd.ExcelWriter, pd.DataFrame.to_excel
+        pd.ExcelWriter, pd.DataFrame.to_excel = NoWorkbook, lambda *a, **k: None
+        try:
+            with tempfile.TemporaryDirectory() as d:
+                sol.save_results(folder_path=d, file_name="results.xlsx")
+                return open(os.path.join(d, "results.txt")).read()
+        finally:
+            pd.ExcelWriter, pd.DataFrame.to_excel = real_writer, real_to_excel
+
+    texts = {}
+    for name in ("akbari", "example"):
+        sol = SOLVERS[name]()
+        sol.prepare_results = lambda: None
+        sol.run(tolerance=1e-4, verbose=0)
+        del sol.prepare_results
+        texts[name] = summary(sol)
+        print(f"--- {name}\n{texts[name]}")
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "result_summaries.npz"),
+                        meta=np.array(json.dumps(dict(generator="oracle/gen_golden.py", kind="result_summaries",
+                                                      reference="cve-mohd/flow-sim snapshot 2026-02-13, run in the build container"))),
+                        **{k: np.array(v) for k, v in texts.items()})
+
+
+def _akbari_solver():
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.hydrograph import Hydrograph
+    from cases.akbari_firoozi import settings as S
+    hyd = Hydrograph(S.hydrograph)
+    us = Boundary(condition='flow_hydrograph', bed_level=S.S_0 * S.length, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='normal_depth', bed_level=0, chainage=S.length)
+    ch = Channel(width=S.width, initial_flow=S.initial_flow, roughness=S.roughness,
+                 upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    return PreissmannSolver(channel=ch, theta=S.theta, time_step=S.preissmann_dt, spatial_step=S.spatial_step,
+                            simulation_time=S.duration, regularization=False)
+
+
+def example_inflow(t):
+    """cases/example/main.py:8-29 restated as data (the module runs the whole case when imported)"""
+    q0, qp = 1000.0, 10000.0
+    rise, hold, fall = 3 * 3600, 6 * 3600, 4 * 3600
+    if t <= 0:
+        return q0
+    if t < rise:
+        return q0 + (qp - q0) * t / rise
+    if t - rise < hold:
+        return qp
+    if t - rise - hold < fall:
+        return qp - (qp - q0) * (t - rise - hold) / fall
+    return q0
+
+
+def _example_solver():
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.lumped_storage import LumpedStorage
+    from src.hydromodel.preissmann import PreissmannSolver
+    hyd = Hydrograph(function=example_inflow)
+    us = Boundary(condition='flow_hydrograph', bed_level=5, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=5, bed_level=0, chainage=20000)
+    ds.set_lumped_storage(LumpedStorage(surface_area=5000 * 250, min_stage=5, solution_boundaries=(0, 200)))
+    ch = Channel(width=250, initial_flow=hyd.get_at(0), roughness=0.027, upstream_boundary=us, downstream_boundary=ds)
+    return PreissmannSolver(channel=ch, theta=0.8, time_step=3600, spatial_step=1000, simulation_time=24 * 3600)
+
+
+SOLVERS = {"akbari": _akbari_solver, "example": _example_solver}
+
+
 CASES = {
     "akbari": case_akbari,
     "example": case_example,
@@ -660,19 +971,28 @@ CASES = {
     "bc_matrix": case_bc_matrix,
     "irregular": case_irregular,
     "storage_general": case_storage_general,
+    "upstream_kinds": case_upstream_kinds,
+    "irr_storage": case_irr_storage,
+    "bench_size": case_bench_size,
+    "storage_callable": case_storage_callable,
+    "result_summaries": case_result_summaries,
 }
+# long-running cases (minutes each): run with --only NAME
+SLOW_CASES = {"gerd_full": case_gerd_full, "gerd_gates": case_gerd_gates, "rmse_curve": case_rmse_curve}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ap.add_argument("--gerd-steps", type=int, default=48)
     a = ap.parse_args()
-    names = list(CASES) + ["gerd"]
+    names = list(CASES) + ["gerd"] + list(SLOW_CASES)
     for name in names:
         if a.only and a.only != name:
             continue
         print(f"[{name}]")
         if name == "gerd":
             case_gerd(a.gerd_steps)
+        elif name in SLOW_CASES:
+            SLOW_CASES[name]()
         else:
             CASES[name]()

@@ -404,7 +404,12 @@ def boundary_eval(bc: BC, geo_node, h, Q, k, dt, Q_old=None, store=None):
             hl = Q * abs(Q) / _k(A, n, R) ** 2 * Lr + Kq * (Q / A) ** 2 / (2 * G)
             d = node_terms(geo_node, np.array([h + bc.bed_level - z_min]), np.array([Q]))  # hw = depth + bed_level
             A, R, n = float(d["A"][0]), float(d["R"][0]), float(d["n_eq"][0])
-            dRdA = float(dR_dA(geo_node, None, section_props(geo_node, np.array([h + bc.bed_level - z_min])))[0])
+            if "irr_npts" in geo_node and int(geo_node["irr_npts"][0]) > 0:     # polyline: central difference, cross_section.py:523-531
+                from . import irregular_oracle as IO
+                c = int(geo_node["irr_npts"][0])
+                dRdA = float(IO.dR_dA(geo_node["irr_x"][0, :c], geo_node["irr_z"][0, :c], h + bc.bed_level))
+            else:
+                dRdA = float(dR_dA(geo_node, None, section_props(geo_node, np.array([h + bc.bed_level - z_min])))[0])
             K = _k(A, n, R)
             dK = (R ** (2.0 / 3.0) + A * 2.0 / 3.0 * R ** (2.0 / 3.0 - 1) * dRdA) / n
             V = Q / A
@@ -556,10 +561,15 @@ def problem_from_fixture(fx, meta, member=None):
         idx = 0 if side == "us" else -1
         bc.bed_slope = None if np.isnan(slope[idx]) else float(slope[idx])
         if kind in ("flow_hydrograph", "stage_hydrograph"):
-            bc.target = np.array(pick("us_target"), dtype=np.float64)
+            own = f"{side}_target"          # older fixtures: one hydrograph per case, stored as us_target
+            bc.target = np.array(pick(own if own in fx else "us_target"), dtype=np.float64)
         bc.initial_depth = meta.get(f"{side}_initial_depth")
         if kind == "rating_curve":
-            if "rating" in meta:
+            if f"{side}_rc_type" in meta:
+                bc.rc_type = meta[f"{side}_rc_type"]
+                bc.rc = dict(a=meta[f"{side}_rc_a"], b=meta[f"{side}_rc_b"], c=meta.get(f"{side}_rc_c"),
+                             shift=meta.get(f"{side}_rc_shift", 0.0))
+            elif "rating" in meta:
                 bc.rc_type, bc.rc = "blend", meta["rating"]
             elif "rc_type" in meta:
                 bc.rc_type = meta["rc_type"]

@@ -191,6 +191,99 @@ def _storage_general(rc_type, losses, trap):
     return PreissmannSolver(channel=ch, theta=0.7, time_step=1200, spatial_step=500, simulation_time=12 * 3600), 1e-6
 
 
+def bc_us_fixed_ds_flow():
+    """reservoir level upstream, closing gate (dipping outflow hydrograph) downstream"""
+    L = 10000.0; S0 = 2e-4; Q0 = 150.0
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=40.0, m_main=1.5, n_main=0.03, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=0.0, b_main=40.0, m_main=1.5, n_main=0.03, bed_slope=S0)
+    hn = xs_d.normal_depth(Q_target=Q0)
+    hyd = Hydrograph(akbari_shape(Q0, -60.0, 2 * 3600.0, 6 * 3600.0))
+    us = Boundary(condition='fixed_depth', bed_level=S0 * L, chainage=0, initial_depth=hn)
+    ds = Boundary(condition='flow_hydrograph', bed_level=0.0, chainage=L, hydrograph=hyd, initial_depth=hn)
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.65, time_step=600, spatial_step=500, simulation_time=8 * 3600), 1e-6
+
+
+def bc_us_rating_ds_stage():
+    """head-dependent inflow upstream (rating curve with negative slope), stage hydrograph downstream"""
+    L = 8000.0; S0 = 3e-4; Q0 = 200.0; h_us = 3.0
+    rc = RatingCurve(); rc.set(type='polynomial', a=0.0, b=-60.0, c=Q0 + 60.0 * (S0 * L + h_us))
+    tab = np.array([[0, 3.0], [3600 * 2, 3.8], [3600 * 5, 3.2], [3600 * 12, 3.0]])
+    us = Boundary(condition='rating_curve', bed_level=S0 * L, chainage=0, initial_depth=h_us, rating_curve=rc)
+    ds = Boundary(condition='stage_hydrograph', bed_level=0.0, chainage=L, initial_depth=3.0, hydrograph=Hydrograph(table=tab))
+    ch = Channel(width=60, initial_flow=Q0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds,
+                 interpolation_method='linear')
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=900, spatial_step=500, simulation_time=8 * 3600), 1e-6
+
+
+def bc_us_normal_ds_stage():
+    """normal depth imposed upstream, stage hydrograph downstream"""
+    L = 12000.0; S0 = 4e-4; Q0 = 180.0
+    xs_u = TrapezoidalSection(z_bed=S0 * L, b_main=50.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    xs_d = TrapezoidalSection(z_bed=0.0, b_main=50.0, m_main=2.0, n_main=0.03, bed_slope=S0)
+    hn = xs_d.normal_depth(Q_target=Q0)
+    tab = np.array([[0, hn], [3600 * 2, hn + 0.6], [3600 * 5, hn + 0.1], [3600 * 12, hn]])
+    us = Boundary(condition='normal_depth', bed_level=S0 * L, chainage=0, initial_depth=hn)
+    ds = Boundary(condition='stage_hydrograph', bed_level=0.0, chainage=L, initial_depth=hn, hydrograph=Hydrograph(table=tab))
+    ch = Channel(initial_flow=Q0, upstream_boundary=us, downstream_boundary=ds, interpolation_method='steady-state')
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=600, spatial_step=500, simulation_time=6 * 3600), 1e-6
+
+
+def irr_storage():
+    """polyline sections in front of a general LumpedStorage (tests/golden/irr_storage.npz)"""
+    L = 6000.0; S0 = 2e-4
+    xu = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); zu = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
+    xd = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zd = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
+    xs_u = IrregularSection(x=xu, z=S0 * L + zu, n=0.03, bed_slope=S0)
+    xs_d = IrregularSection(x=xd, z=zd, n=0.034, bed_slope=S0)
+    hyd = Hydrograph(akbari_shape(40.0, 260.0, 1 * 3600.0, 3 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=S0 * L, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=2.2, bed_level=0.0, chainage=L)
+    stages = np.arange(0.0, 12.01, 0.25)
+    curve = np.column_stack([stages, 6.0e4 + 1.5e4 * stages + 500.0 * stages ** 2])
+    rc = RatingCurve(); rc.set(type='polynomial', a=4.0, b=6.0, c=0.0)
+    ss = LumpedStorage(surface_area=None, min_stage=1.0, solution_boundaries=(0, 12), rating_curve=rc)
+    ss.set_area_curve(curve, alpha=1.0, beta=0.0)
+    ss.capture_losses = True; ss.reservoir_length = 300.0; ss.K_q = 0.2
+    ds.set_lumped_storage(ss)
+    ch = Channel(initial_flow=40.0, upstream_boundary=us, downstream_boundary=ds)
+    ch.set_cross_sections([0.0, L], [xs_u, xs_d])
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=300, spatial_step=500, simulation_time=3 * 3600), 1e-6
+
+
+# ---- boundary plugins without a device form: evaluated on the host every Newton iteration (FS_BC_HOST_ROW) ----
+def weir_outflow(stage):
+    """reservoir outlet: nothing below the crest, a broad-crested weir above it (a Python callable as rating curve)"""
+    crest = 6.0
+    return 0.0 if stage <= crest else 55.0 * (stage - crest) ** 1.5
+
+
+def storage_callable_rc():
+    """LumpedStorage whose outflow curve is a Python callable (tests/golden/storage_callable_rc.npz)"""
+    L = 10000.0
+    hyd = Hydrograph(akbari_shape(200.0, 900.0, 3 * 3600.0, 9 * 3600.0))
+    us = Boundary(condition='flow_hydrograph', bed_level=2.0, chainage=0, hydrograph=hyd)
+    ds = Boundary(condition='fixed_depth', initial_depth=5, bed_level=0, chainage=L)
+    rc = RatingCurve(); rc.function = weir_outflow; rc.defined = True
+    ds.set_lumped_storage(LumpedStorage(surface_area=8.0e5, min_stage=4.0, solution_boundaries=(0, 30), rating_curve=rc))
+    ch = Channel(width=100, initial_flow=200.0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds)
+    return PreissmannSolver(channel=ch, theta=0.7, time_step=1200, spatial_step=500, simulation_time=12 * 3600), 1e-6
+
+
+def gerd_gates():
+    """cases/gerd_roseires with operated gates (RoseiresRatingCurve(smooth=False): opens at level 27, closes at 36) under
+    a flood wave scaled by 8 (tests/golden/gerd_gates.npz)"""
+    from cases.gerd_roseires.model import build
+    from cases.gerd_roseires import settings as S
+    solver, _ = build(inflow_hyd_func=None, sim_duration=40 * 3600, inflow_scale=8.0, smooth_gates=False)
+    return solver, S.tolerance
+
+
+HOST_ROW_BUILDERS = {"storage_callable_rc": storage_callable_rc, "gerd_gates": gerd_gates}
+
+
 def storage_curve_poly_losses():
     return _storage_general('polynomial', True, False)
 
@@ -205,4 +298,6 @@ def storage_curve_closed():
 
 BUILDERS = {"storage_curve_poly_losses": storage_curve_poly_losses, "storage_curve_power_trap": storage_curve_power_trap,
             "storage_curve_closed": storage_curve_closed, "irr_single": irr_single, "irr_levee": irr_levee, "irr_mixed": irr_mixed, "gerd": gerd, "akbari": akbari, "example": example, "bc_stage_fixed": bc_stage_fixed, "bc_trap_poly": bc_trap_poly,
-            "bc_compound_normal": bc_compound_normal}
+            "bc_compound_normal": bc_compound_normal, "bc_us_fixed_ds_flow": bc_us_fixed_ds_flow,
+            "bc_us_rating_ds_stage": bc_us_rating_ds_stage, "bc_us_normal_ds_stage": bc_us_normal_ds_stage,
+            "irr_storage": irr_storage}

@@ -114,3 +114,155 @@ def test_newton_residual_trace_matches_reference(name, capsys):
         got = solver.residual_norms[k, :len(ref)]
         assert np.all(solver.residual_norms[k, len(ref):] == 0)
         np.testing.assert_allclose(got, ref, rtol=1e-6, atol=1e-9 * ref[0] + 1e-12)
+
+
+@pytest.mark.parametrize("name", sorted(CB.HOST_ROW_BUILDERS))
+def test_plugins_without_a_device_form_run_through_host_rows(name):
+    """The plugin contract is "any object with discharge(stage, time) / dQ_dz" (rating_curve.py:32-63, :132-147) and a
+    LumpedStorage may carry any rating curve (lumped_storage.py:24-35).  Plugins without a device form - operated gates
+    that move with time and their own history, a Python callable as reservoir outlet - run with their boundary row
+    evaluated on the host before every Newton iteration (FS_BC_HOST_ROW, one kernel launch per iteration); the rest of
+    the iteration is the same kernel.  Against fixtures the reference produced with the same plugins."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, tol = CB.HOST_ROW_BUILDERS[name]()
+    assert not solver.channel.downstream_boundary.has_device_form()
+    solver.run(tolerance=tol, verbose=0)
+    assert rel(solver.depth, fx["depth"], 1e-3) <= TOL
+    assert rel(solver.flow, fx["flow"], 1.0) <= TOL
+    assert np.array_equal(solver.iterations, fx["iters"])
+    assert rel(solver.unknowns, fx["final_unknowns"], 1e-3) <= 1e-7
+    if name == "gerd_gates":       # the gates did move: the outflow jumps by an order of magnitude and comes back
+        q = solver.flow[:, -1]
+        assert q[26] < 2200 and q[27] > 15000 and q[36] < 2200
+    else:
+        st = solver.channel.downstream_boundary.lumped_storage
+        got = np.array(st.stage_hydrograph)[1:, 1]
+        assert rel(got, fx["storage_stage"][:, 1], 1e-3) <= TOL
+
+
+def test_one_iteration_per_launch_equals_the_fused_loop():
+    """fs_batch_iterate (one Newton iteration per launch, iteration count carried across launches) against fs_batch_step
+    (the whole loop in one launch) on device-evaluated boundaries: the same kernel code, so the same bits."""
+    from fixture_batch import batch_from_problems
+    for name, B in (("gerd", 1), ("storage_curve_poly_losses", 1), ("irr_mixed", 1), ("gerd_ensemble", 8)):
+        fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+        probs = [O.problem_from_fixture(fx, meta, m) for m in (range(B) if meta.get("B") else [None])]
+        override = [float(p.geo["n_main"][0]) for p in probs] if B > 1 else None
+        mode = "irregular" if name.startswith("irr") else "table"
+        n = min(probs[0].nt - 1, 8)
+        with batch_from_problems(probs, mode=mode, n_main_override=override) as a, \
+                batch_from_problems(probs, mode=mode, n_main_override=override) as b:
+            a.step(n)
+            launches = 0
+            while b.level < n:
+                b.iterate()
+                launches += 1
+            its = a.iterations(0, n + 1)
+            assert launches == int(its.max(axis=1).sum())          # members wait for the slowest one of a level
+            assert np.array_equal(its, b.iterations(0, n + 1))
+            assert np.array_equal(a.hydrographs(0, n + 1), b.hydrographs(0, n + 1))
+            for x, y in zip(a.state() + a.guess() + a.history_arrays(0, n + 1), b.state() + b.guess() + b.history_arrays(0, n + 1)):
+                assert np.array_equal(x, y)
+            assert np.all(b.status() == 0)
+
+
+def test_restart_continues_bit_exactly():
+    """A run stopped at level k and continued in a NEW batch from (state, Newton start vector, reservoir stage) gives the
+    bits of the uninterrupted run: after the first level the start vector differs from the state, so both
+    travel (fs_batch_restart)."""
+    from fixture_batch import batch_from_problems
+    for name in ("example", "synthetic_rect_512", "gerd", "storage_curve_power_trap"):
+        fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+        probs = [O.problem_from_fixture(fx, meta, m) for m in (range(meta["B"]) if meta.get("B") else [None])]
+        nt = min(probs[0].nt, 13)
+        k = nt // 2
+        with batch_from_problems(probs, history=False) as a:
+            a.step(nt - 1)
+            want = a.hydrographs(0, nt), a.iterations(0, nt), a.state(), a.guess()
+        with batch_from_problems(probs, history=False) as b:
+            b.step(k)
+            snap = b.state() + b.guess() + (b.storage_stage(),)
+            first = b.hydrographs(0, k + 1)
+        assert not np.array_equal(snap[0], snap[2])                 # state != Newton start vector
+        with batch_from_problems(probs, history=False) as c:
+            c.restart(k, *snap)
+            assert c.level == k
+            c.step(nt - 1 - k)
+            assert np.all(c.status() == 0)
+            assert np.array_equal(c.hydrographs(k, nt - k), want[0][k:])
+            assert np.array_equal(first, want[0][:k + 1])
+            assert np.array_equal(c.iterations(k + 1, nt - 1 - k), want[1][k + 1:])
+            for x, y in zip(c.state() + c.guess(), want[2] + want[3]):
+                assert np.array_equal(x, y)
+
+
+def test_calibration_rmse_curve_matches_the_reference():
+    """cases/gerd_roseires/n_calibrate - the ten-member Manning-n study as ONE device batch - against
+    the curve the reference's own loop produced (n_calibrate.py:55-67 over model.run; tests/golden/rmse_curve.npz;
+    SURVEY F9 quotes 5.85 / 2.65 / 1.74 at n = 0.02 / 0.0422 / 0.06)."""
+    from cases.gerd_roseires.n_calibrate import rmse_curve, H_target, Q_gauge
+    fx = np.load(os.path.join(GOLDEN, "rmse_curve.npz"))
+    assert np.array_equal(H_target, fx["H_target"]) and np.array_equal(Q_gauge, fx["Q"])
+    got = np.array(rmse_curve(fx["n_values"]))
+    np.testing.assert_allclose(got, fx["rmse"], rtol=1e-8, atol=0)
+    assert abs(got[0] - 5.85) < 5e-3 and abs(got[5] - 2.65) < 5e-3 and abs(got[-1] - 1.74) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["akbari", "example"])
+def test_result_summary_text_matches_the_reference(name, tmp_path):
+    """Solver.save_results' text summary (solver.py:188-233): the .txt the mirror writes next to its result tables is,
+    character for character, the one the reference wrote for the same case (tests/golden/result_summaries.npz)."""
+    fx = np.load(os.path.join(GOLDEN, "result_summaries.npz"))
+    solver, tol = CB.BUILDERS[name]()
+    solver.run(tolerance=tol, verbose=0)
+    solver.save_results(str(tmp_path), "results.xlsx")
+    assert open(os.path.join(tmp_path, "results.txt")).read() == str(fx[name])
+
+
+def test_derived_fields_can_stay_on_the_device():
+    """fs_batch_derive_device: the prepare_results kernel with its outputs left in HBM (buffers owned and reused by the
+    handle); the host-copy entry point is the same kernel plus the download."""
+    import ctypes
+    from fixture_batch import batch_from_problems
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "akbari.npz"))
+    p = O.problem_from_fixture(fx, meta)
+    with batch_from_problems([p]) as b:
+        b.step(p.nt - 1)
+        ptr1 = b.derive_device(0, p.nt, fields=2 | 8)             # area, Froude number
+        assert set(ptr1) == {"area", "froude_number"} and all(ptr1.values())
+        ptr2 = b.derive_device(0, p.nt, fields=2 | 8)
+        assert ptr1 == ptr2                                      # no reallocation for a call of the same size
+        host = b.derive(0, p.nt, fields=("area", "froude_number"))
+        assert rel(host["area"][:, 0], fx["derived_area"], 1e-6) <= TOL
+        assert rel(host["froude_number"][:, 0], fx["derived_froude_number"], 1e-6) <= TOL
+
+
+def test_batches_on_two_devices_in_one_process():
+    """every entry point switches to its batch's device and back: a batch on device 1 configured and stepped
+    while device 0 is current, next to a batch on device 0"""
+    from flowsim_amd import _abi as A
+    if A.device_count() < 2:
+        pytest.skip("one GPU visible")
+    from fixture_batch import batch_from_problems
+    import fixture_batch as FB
+    from flowsim_amd import PreissmannBatch
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "akbari.npz"))
+    p = O.problem_from_fixture(fx, meta)
+    real = PreissmannBatch.__init__
+    out = []
+    for dev in (0, 1):
+        def init(self, *a, **k):
+            k["device"] = dev
+            real(self, *a, **k)
+        FB.PreissmannBatch.__init__ = init
+        try:
+            b = batch_from_problems([p])
+        finally:
+            FB.PreissmannBatch.__init__ = real
+        out.append(b)
+    for b in out:
+        b.step(p.nt - 1)
+    for b in out:
+        h, Q = b.history_arrays()
+        assert rel(Q[:, 0], fx["flow"], 1.0) <= TOL
+        b.close()

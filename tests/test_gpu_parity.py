@@ -10,13 +10,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, fixture_paths
 from oracle import preissmann_oracle as O
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-8
-FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+FIXTURES = fixture_paths()
 
 
 def boundary_kind(bc):

@@ -33,6 +33,9 @@ def check(solver, fx, meta, mem=None):
     if ch.upstream_boundary.hydrograph is not None:
         tgt = ch.upstream_boundary.hydrograph.sample(meta["nt"], solver.time_step)
         np.testing.assert_allclose(tgt, pick("us_target"), rtol=1e-14)
+    if ch.downstream_boundary.hydrograph is not None:
+        tgt = ch.downstream_boundary.hydrograph.sample(meta["nt"], solver.time_step)
+        np.testing.assert_allclose(tgt, pick("ds_target"), rtol=1e-14)
 
 
 @pytest.mark.parametrize("name", sorted(CB.BUILDERS))
@@ -41,6 +44,31 @@ def test_setup_matches_reference(name):
     solver, tol = CB.BUILDERS[name]()
     assert tol == meta["tolerance"] and solver.theta == meta["theta"]
     check(solver, fx, meta)
+
+
+@pytest.mark.parametrize("name", sorted(CB.HOST_ROW_BUILDERS))
+def test_host_evaluated_boundary_row_matches_reference(name):
+    """Boundary plugins without a device form (a rating curve that moves with time, a reservoir with a callable outflow
+    curve): set-up as the reference's, no device form, and the row the mirror evaluates on the host at the initial
+    state - condition_residual, df_dh, df_dQ (boundary.py:56-242) - equals the last residual / the last two Jacobian
+    entries of the reference's first Newton iteration."""
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    solver, tol = CB.HOST_ROW_BUILDERS[name]()
+    check(solver, fx, meta)
+    ds = solver.channel.downstream_boundary
+    assert meta["host_evaluated"] == "downstream" and not ds.has_device_form() and solver.channel.upstream_boundary.has_device_form()
+    ic = fx["initial_conditions"]
+    dt = solver.time_step
+    h, Q = ic[-1, 0], ic[-1, 1]
+    vol = 0.5 * (Q + Q) * dt
+    res = ds.condition_residual(depth=h, flow=Q, time=dt, duration=dt, vol_in=vol)
+    assert abs(res - fx["R0"][-1]) <= 1e-10 * max(1.0, abs(fx["R0"][-1]))
+    dh = ds.df_dh(depth=h, flow_rate=Q, time=dt)
+    dq = ds.df_dQ(depth=h, flow_rate=Q, duration=dt, time=dt, vol_in=vol)
+    if "J0" in fx.files:
+        np.testing.assert_allclose([dh, dq], fx["J0"][-2:], rtol=1e-9, atol=1e-12)
+    else:
+        assert np.isfinite(dh) and dq == 1
 
 
 @pytest.mark.parametrize("name", ["irr_single", "irr_levee", "irr_mixed"])
@@ -180,3 +208,28 @@ def test_vectorised_gvf_profiles_match_per_member_setup():
     lead, _ = CB.gerd_member(float(ns[0]))
     ic = gvf_profiles(lead.channel, ns)
     np.testing.assert_allclose(ic, fx["initial_conditions"], rtol=1e-11, atol=1e-12)
+
+
+def test_fitted_rating_curve_device_form_agrees_with_its_python_evaluation():
+    """RatingCurve.fit(scale=True) keeps a numpy Polynomial: discharge() evaluates it at the stage, dQ_dz() its derivative
+    at stage + stage_shift (rating_curve.py:51-52, :139-141).  The device form exists only where both agree with one
+    abscissa (no shift, degree <= 2) and then reproduces discharge / dQ_dz; anything else goes to the host path."""
+    from flowsim_amd.hydromodel import RatingCurve
+    z = np.linspace(101.0, 106.0, 9)
+    q = 3.0 * (z - 100) ** 2 + 11.0 * (z - 100) + 5.0
+    rc = RatingCurve(); rc.fit(discharges=q, stages=z, stage_shift=0, type='polynomial', scale=True)
+    kind, p = rc.device_spec(bed_level=100.0)
+    assert kind == "poly" and p["stage_shift"] == 0.0
+    for s in (101.5, 103.25, 105.0):
+        x = s + p["stage_shift"]
+        assert abs(p["a"] * x * x + p["b"] * x + p["c"] - rc.discharge(s)) <= 1e-9 * abs(rc.discharge(s))
+        assert abs(2 * p["a"] * x + p["b"] - rc.dQ_dz(s)) <= 1e-9 * abs(rc.dQ_dz(s))
+    shifted = RatingCurve(); shifted.fit(discharges=q, stages=z, stage_shift=-100.0, type='polynomial', scale=True)
+    cubic = RatingCurve(); cubic.fit(discharges=q, stages=z, stage_shift=0, type='polynomial', scale=True, degree=3)
+    free = RatingCurve(); free.function = lambda stage: 2.0 * stage; free.defined = True
+    for r in (shifted, cubic, free):
+        with pytest.raises(NotImplementedError):
+            r.device_spec(bed_level=100.0)
+    unscaled = RatingCurve(); unscaled.fit(discharges=q, stages=z, stage_shift=-100.0, type='polynomial', scale=False)
+    kind, p = unscaled.device_spec(bed_level=100.0)               # plain a, b, c: one abscissa, the shift is exact
+    assert kind == "poly" and p["stage_shift"] == -100.0 and abs(p["a"] - 3.0) < 1e-8

@@ -6,14 +6,13 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, fixture_paths
 from oracle import c_oracle as CO
 from oracle import preissmann_oracle as O
 
 # the C restatement covers the trapezoid family with closed-form boundaries; polyline channels and the
 # brentq-based general LumpedStorage are pinned by the numpy oracle (test_oracle_irregular.py, test_oracle_golden.py)
-FIXTURES = [p for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
-            if not os.path.basename(p).startswith(("irr_", "storage_curve_"))]
+FIXTURES = [p for p in fixture_paths() if not os.path.basename(p).startswith(("irr_", "storage_curve_"))]
 
 
 def rel_err(got, want, floor):

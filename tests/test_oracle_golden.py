@@ -11,10 +11,10 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, fixture_paths
 from oracle import preissmann_oracle as O
 
-FIXTURES = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+FIXTURES = fixture_paths()
 TOL = 1e-8
 
 
@@ -35,7 +35,8 @@ def test_fixtures_present():
     names = {os.path.basename(p) for p in FIXTURES}
     for need in ("akbari.npz", "example.npz", "gerd.npz", "gerd_ensemble.npz", "synthetic_rect_64.npz",
                  "synthetic_rect_512.npz", "synthetic_trap_64.npz", "bc_stage_fixed.npz",
-                 "bc_trap_poly.npz", "bc_compound_normal.npz"):
+                 "bc_trap_poly.npz", "bc_compound_normal.npz", "c3_4096.npz", "c5_512.npz", "gerd_full.npz",
+                 "bc_us_fixed_ds_flow.npz", "bc_us_rating_ds_stage.npz", "bc_us_normal_ds_stage.npz"):
         assert need in names
 
 
@@ -49,10 +50,14 @@ def test_first_iteration_residual_and_jacobian(path):
         p = O.problem_from_fixture(fx, meta, mem)
         store = {"Y_prev": None} if p.ds.storage is not None else None
         R, data, _ = O.assemble(p, p.h0, p.Q0, p.h0, p.Q0, 1, store)
-        R0, J0 = pick(fx, "R0", mem, 1), pick(fx, "J0", mem, 1)
-        assert R.shape == R0.shape and data.shape == J0.shape
+        R0 = pick(fx, "R0", mem, 1)
+        assert R.shape == R0.shape
         scale = max(1.0, float(np.max(np.abs(R0))))
         assert np.max(np.abs(R - R0)) <= 1e-10 * scale
+        if "J0" not in fx.files:
+            continue                     # benchmark-size fixtures keep the residual vector only
+        J0 = pick(fx, "J0", mem, 1)
+        assert data.shape == J0.shape
         # polyline nodes: dA/dh and dR/dA are central differences with dh = 1e-6 (cross_section.py:523-538),
         # their cancellation noise (~1e-10 relative, summation order) enters the Jacobian
         assert rel_err(data, J0, 1e-6) <= (2e-8 if "geo_irr_npts" in fx.files else 1e-9)
