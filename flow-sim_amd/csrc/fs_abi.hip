@@ -56,7 +56,7 @@ struct DeviceGuard {
 typedef FsLaunchFn LaunchFn;
 typedef const void *KernelPtr;
 
-// full   == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
+// full   == 1: no per-row selects, valid only for N = 64*W*M
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
 struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; };   // diag == 0: no history / trace stores
@@ -104,13 +104,12 @@ const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRA
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 
 bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, bool need_diag, bool need_any) {
-  const int cells = N - 1;
   const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
   if (e.dtype != dtype || e.sec != sec) return false;
-  const int cap = 64 * e.W * e.M;
-  if (cap < cells) return false;
-  if (e.full && !(cells == cap || cells == cap - 1)) return false;
+  const int cap = 64 * e.W * e.M;       // rows of the scalar system: N - 1 cells + the downstream boundary row
+  if (cap < N) return false;
+  if (e.full && N != cap) return false;
   if (!e.diag && need_diag) return false;
   if (need_any && e.bck != -1) return false;
   if (e.bck == 0 && beyond0) return false;
@@ -144,7 +143,7 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
         (e.M == best->M && e.W == best->W && spec > bspec))
       best = &e;
   }
-  if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4097 nodes)";
+  if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4096 nodes)";
   return best;
 }
 

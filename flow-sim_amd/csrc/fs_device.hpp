@@ -156,7 +156,8 @@ template <typename R> struct NodeTerms {
   R eA;   // (dSe/dA in the reference's mixed convention) * dA/dh      (channel.py:71-87)
   R eQ;   // dSe/dQ                              (channel.py:89-105)
   R v;    // Q / A
-};
+  R rT;   // 1 / T: the continuity row's dh coefficient is T/(2dt) on both nodes (preissmann.py:431-447), its reciprocal scales
+};        // the node's momentum entries into the characteristic-like unknowns of the solve (below)
 
 // trapezoidal section parameters at one node (cross_section.py:569-613)
 template <typename R> struct SecParams {
@@ -186,6 +187,7 @@ __device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q
   t.eQ = R(2) * aQ * iK2;                                          // hydraulics.py:92
   t.eA = R(-2) * t.Se * fma_(R(2.0 / 3.0) * b, rP, R(1)) * rh;  // hydraulics.py:75 times T
   t.v = Q * rA;
+  t.rT = rb;
   return t;
 }
 
@@ -211,9 +213,10 @@ __device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R 
   t.T = T;
   t.Se = Q * aQ * iK2;
   t.eQ = R(2) * aQ * iK2;
-  const R f = R(1) + R(2.0 / 3.0) * (R(1) - sm2 * A * rT * rP);
+  const R f = fma_(R(2.0 / 3.0), fma_(-(sm2 * A * rT), rP, R(1)), R(1));
   t.eA = R(-2) * t.Se * f * rA * T;
   t.v = Q * rA;
+  t.rT = rT;
   return t;
 }
 
@@ -227,7 +230,7 @@ template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ?
 // conveyance of a single sub-section, hydraulics.py:15-26
 template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) * frcp(n); }
 
-template <typename R> struct GeneralProps { R A, P, Rh, T, K, neq, dRdA, dKdA, y13; };
+template <typename R> struct GeneralProps { R A, P, Rh, T, rT, K, neq, dRdA, dKdA, y13; };
 
 // General trapezoid family (rectangle / simple / compound), straight from the reference including
 // the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
@@ -296,7 +299,7 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
   g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * rT)) * (rP * rP);   // :766-790
   g.dKdA = A <= R(0) ? R(0)
                      : (R23 + A * R(2.0 / 3.0) * y13 * g.dRdA) * frcp(neq);                        // :756-764
-  g.A = A; g.P = P; g.T = T; g.K = K; g.neq = neq; g.y13 = y13;
+  g.A = A; g.P = P; g.T = T; g.rT = rT; g.K = K; g.neq = neq; g.y13 = y13;
   return g;
 }
 
@@ -352,6 +355,7 @@ __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h
   R Se = Sf, eQ = R(2) * aQ * iK2;
   add_curvature(s.curv, g.A, g.T, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
   t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q * frcp(g.A);
+  t.rT = g.rT;
   return t;
 }
 
@@ -703,94 +707,70 @@ __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<
 }
 
 // ---------------------------------------------------------------------------------------------
-// segment algebra: a "segment" is the pair of linear relations left between the first and the
-// last node of a run of cells once the interior nodes are eliminated,
-//     C-like row:  pc . d_first + sc . d_last = qc
-//     M-like row:  pm . d_first + sm . d_last = qm          (d = (dh, dQ))
-// A single cell is a segment (rows = continuity, momentum).  merge() eliminates the node shared by
-// two adjacent segments, pivoting on (M-like row of the left, C-like row of the right): the block
-// row order of the classical Preissmann double sweep, no pivoting (checked against SuperLU in
-// tests/test_partition_model.py; see pivot_det below for where the pivot block degenerates).
+// The linear solve (reference: scipy.sparse.linalg.spsolve on the 2N x 2N banded Jacobian, preissmann.py:146).
+//
+// Characteristic-like unknowns.  The continuity row of cell i (preissmann.py:431-491) carries the same two numbers on
+// both of its nodes: t = T/(2dt) on dh and -+cq = theta/dx on dQ.  With
+//       p_i = t_i dh_i + cq dQ_i ,   m_i = t_i dh_i - cq dQ_i
+// it reads  m_i + p_{i+1} = rc_i : every p but the first is an m and a number - no division, no pivot.  What remains is
+// ONE scalar tridiagonal system in (p_0, m_0, ..., m_{N-1}); row i is the momentum row of cell i,
+//       al_i p_i + D_i m_i + de_i m_{i+1} = rho0_i ,     p_i = rc_{i-1} - m_{i-1}   (i > 0)
+//       al, be = pm0/(2t_i) +- pm1/(2cq) ,  ga, de = sm0/(2t_{i+1}) +- sm1/(2cq) ,  D = be - ga ,  rho0 = qm - ga rc
+// followed by the downstream boundary row (on p_{N-1}, m_{N-1}) and identity rows up to the lane grid; the upstream
+// boundary row closes the system on the left.  Frictionless and subcritical the rows are diagonally dominant
+// (|D| = 2(a + k) against |a - k + v| + |a - k - v|, a = theta dt (c^2 - v^2)/dx, k = dx/(4 theta dt)), friction adds to
+// the diagonal: the elimination needs no pivoting, and it has none of the singular 2x2 pivot blocks the block order of
+// the classical double sweep meets on steep shallow reaches (tests/partition_model.py is the numpy model of all this,
+// tests/test_partition_model.py compares it with SuperLU).
+//
+// A run of rows [a, b) is a "segment": what is left between its four boundary unknowns once the interior is eliminated,
+//       up  :  u1 p_a +    m_a + u3 m_{b-1}           = ru        (the first row, its far unknown substituted)
+//       down:  d1 p_a        + d2 m_{b-1} + d3 m_b    = rd        (forward elimination, fill-in column of p_a)
+// plus rc of its last row, which links the next segment: p_b = rc - m_{b-1}.  The coefficient of m_a in the up row is 1
+// by construction and stays 1 through every merge, so a segment is 8 numbers.
 // ---------------------------------------------------------------------------------------------
-template <typename R> struct Seg { R pc0, pc1, sc0, sc1, qc, pm0, pm1, sm0, sm1, qm; };
-// what is needed to recover the eliminated node from the two outer ones
-template <typename R> struct Elim { R w10, w11, w20, w21, pm0, pm1, qm, sc0, sc1, qc; };
+template <typename R> struct Row { R al, D, de, rho0, rc; };                 // one row of the scalar system
+template <typename R> struct Seg { R u1, u3, ru, d1, d2, d3, rd, rc; };
+// what the way down needs to recover the separator m_{b-1} = -A1 p_a + A2 m_{c-1} + A3 of a merge and the p of the
+// right half's first row, p_b = rc - m_{b-1}
+template <typename R> struct Elim { R A1, A2, A3, rc; };
 
-// Determinant of the pivot block {M-like row of the left segment, C-like row of the right one} at the
-// shared node.  The block is singular where friction balances the celerity terms of a cell - for a wide
-// section roughly at depth h* = (5/3) Se dx, i.e. on grids coarser than the backwater length h/S0
-// (steep, shallow reaches: SURVEY 8d C5 at S0 ~ 9e-4, dx = 500 m, h ~ 0.65 m) - although the system
-// itself is well conditioned there (the reference's SuperLU pivots around it, preissmann.py:139).
-// fp64 rides through: a determinant of relative size d costs log10(1/d) of 16 digits of one Newton
-// step, and the residual stays exact.  fp32 has 7 digits and hits exact zeros about once per 1e6
-// reach-runs (inf -> NaN), so there the pivot entry sm0 is moved until |det| >= 2^-10 of its two
-// products: the elimination is then exact for a Jacobian with one entry perturbed by <= 0.2 %, which
-// Newton absorbs (static pivoting).  Returns det; sm0 is updated in place.
-#ifndef FS_PIVOT_FLOOR_F32
-#define FS_PIVOT_FLOOR_F32 1
-#endif
 __device__ __forceinline__ float abs_mod(float x) { return __builtin_fabsf(x); }     // source modifier, no instruction
 __device__ __forceinline__ double abs_mod(double x) { return __builtin_fabs(x); }
-template <typename R>
-__device__ __forceinline__ R pivot_det(R &sm0, R sm1, R pc0, R pc1) {
-  if (sizeof(R) == 8 || !FS_PIVOT_FLOOR_F32) return sm0 * pc1 - sm1 * pc0;
-  const R t1 = sm0 * pc1, t2 = sm1 * pc0;
-  R det = t1 - t2;
-  const R thr = R(1.0 / 1024.0) * (abs_mod(t1) + abs_mod(t2));
-  if (__builtin_expect(abs_mod(det) < thr, 0)) {
-    det = det < R(0) ? -thr : thr;
-    sm0 = (det + t2) / pc1;          // |t1| ~ |t2| ~ 512 thr here, so pc1 != 0
-  }
-  return det;
-}
 
+// merges X = [a, b) and Y = [b, c): m_{b-1} is eliminated from {X.down, Y.up}; m_b appears in no outer row and drops out
 template <typename R>
-__device__ __forceinline__ void merge(const Seg<R> &A_, const Seg<R> &B, Seg<R> &O, Elim<R> &e) {
-  Seg<R> A = A_;
-  const R det = pivot_det(A.sm0, A.sm1, B.pc0, B.pc1);
+__device__ __forceinline__ void merge(const Seg<R> &X, const Seg<R> &Y, Seg<R> &Z, Elim<R> &e) {
+  const R ru2 = fma_(-Y.u1, X.rc, Y.ru);          // Y's rows on m_{b-1} instead of p_b
+  const R rd2 = fma_(-Y.d1, X.rc, Y.rd);
+  const R det = fma_(X.d3, Y.u1, X.d2);           // | d2 d3 ; -u1' 1 |
   const R r = frcp(det);
-  const R w10 = B.pc1 * r, w11 = -B.pc0 * r;      // D^-1, column of the M-like pivot row
-  const R w20 = -A.sm1 * r, w21 = A.sm0 * r;      // D^-1, column of the C-like pivot row
-  const R al = A.sc0 * w10 + A.sc1 * w11, be = A.sc0 * w20 + A.sc1 * w21;
-  const R ga = B.pm0 * w10 + B.pm1 * w11, ep = B.pm0 * w20 + B.pm1 * w21;
-  e.w10 = w10; e.w11 = w11; e.w20 = w20; e.w21 = w21;
-  e.pm0 = A.pm0; e.pm1 = A.pm1; e.qm = A.qm; e.sc0 = B.sc0; e.sc1 = B.sc1; e.qc = B.qc;
-  Seg<R> o;
-  o.pc0 = A.pc0 - al * A.pm0; o.pc1 = A.pc1 - al * A.pm1;
-  o.sc0 = -be * B.sc0;        o.sc1 = -be * B.sc1;
-  o.qc = A.qc - al * A.qm - be * B.qc;
-  o.pm0 = -ga * A.pm0;        o.pm1 = -ga * A.pm1;
-  o.sm0 = B.sm0 - ep * B.sc0; o.sm1 = B.sm1 - ep * B.sc1;
-  o.qm = B.qm - ga * A.qm - ep * B.qc;
-  O = o;
+  const R g2 = X.d3 * r;
+  const R A1 = r * X.d1, A2 = g2 * Y.u3, A3 = fma_(r, X.rd, -(g2 * ru2));
+  e.A1 = A1; e.A2 = A2; e.A3 = A3; e.rc = X.rc;
+  Seg<R> z;
+  z.u1 = fma_(-X.u3, A1, X.u1); z.u3 = X.u3 * A2; z.ru = fma_(-X.u3, A3, X.ru);
+  z.d1 = Y.d1 * A1; z.d2 = fma_(-Y.d1, A2, Y.d2); z.d3 = Y.d3; z.rd = fma_(Y.d1, A3, rd2);
+  z.rc = Y.rc;
+  Z = z;
 }
 
-template <typename R>
-__device__ __forceinline__ void back(const Elim<R> &e, R dL0, R dL1, R dR0, R dR1, R &d0, R &d1) {
-  const R sig = e.qm - (e.pm0 * dL0 + e.pm1 * dL1);
-  const R tau = e.qc - (e.sc0 * dR0 + e.sc1 * dR1);
-  d0 = e.w10 * sig + e.w20 * tau;
-  d1 = e.w11 * sig + e.w21 * tau;
+// the separator of a merge from the two numbers its group carries on the way down
+template <typename R> __device__ __forceinline__ R separator(const Elim<R> &e, R pL, R mR) {
+  return fma_(-e.A1, pL, fma_(e.A2, mR, e.A3));
 }
 
-// closes segment S (first node .. last node of the reach) with the two boundary rows
+// Root segment S (all rows; nothing right of its last row, so d3 multiplies no unknown) and the upstream boundary row
+// aU p_0 + bU m_0 = rU  ->  p_0, m_0 and the m of the last row.
 template <typename R>
-__device__ __forceinline__ void close_system(const Seg<R> &S, const BCRow<R> &U, const BCRow<R> &Dn,
-                                             R &a0, R &a1, R &z0, R &z1) {
-  // block row 0 = {U, C-like}: d_first = g - x * (sc . d_last)
-  const R r0 = frcp(U.dh * S.pc1 - U.dq * S.pc0);
-  const R ru = -U.res, rd = -Dn.res;
-  const R g0 = (S.pc1 * ru - U.dq * S.qc) * r0, g1 = (-S.pc0 * ru + U.dh * S.qc) * r0;
-  const R x0 = -U.dq * r0, x1 = U.dh * r0;
-  const R k = S.pm0 * x0 + S.pm1 * x1;
-  const R m0 = S.sm0 - k * S.sc0, m1 = S.sm1 - k * S.sc1;
-  const R rm = S.qm - (S.pm0 * g0 + S.pm1 * g1);
-  const R r1 = frcp(m0 * Dn.dq - m1 * Dn.dh);
-  z0 = (Dn.dq * rm - m1 * rd) * r1;
-  z1 = (-Dn.dh * rm + m0 * rd) * r1;
-  const R t = S.sc0 * z0 + S.sc1 * z1;
-  a0 = g0 - x0 * t;
-  a1 = g1 - x1 * t;
+__device__ __forceinline__ void close_root(const Seg<R> &S, R aU, R bU, R rU, R &p0, R &m0, R &mlast) {
+  const R r = frcp(S.d2);
+  const R f = S.u3 * r;
+  const R e1 = fma_(-f, S.d1, S.u1), e3 = fma_(-f, S.rd, S.ru);       // e1 p_0 + m_0 = e3
+  const R rdet = frcp(fma_(-bU, e1, aU));
+  p0 = fma_(-bU, e3, rU) * rdet;
+  m0 = fma_(-e1, p0, e3);
+  mlast = fma_(-S.d1, p0, S.rd) * r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -831,10 +811,9 @@ template <int D, typename R> __device__ __forceinline__ R tree_from_below(R v) {
 }
 template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(const Seg<R> &s) {
   Seg<R> o;
-  o.pc0 = tree_from_below<D>(s.pc0); o.pc1 = tree_from_below<D>(s.pc1); o.sc0 = tree_from_below<D>(s.sc0);
-  o.sc1 = tree_from_below<D>(s.sc1); o.qc = tree_from_below<D>(s.qc); o.pm0 = tree_from_below<D>(s.pm0);
-  o.pm1 = tree_from_below<D>(s.pm1); o.sm0 = tree_from_below<D>(s.sm0); o.sm1 = tree_from_below<D>(s.sm1);
-  o.qm = tree_from_below<D>(s.qm);
+  o.u1 = tree_from_below<D>(s.u1); o.u3 = tree_from_below<D>(s.u3); o.ru = tree_from_below<D>(s.ru);
+  o.d1 = tree_from_below<D>(s.d1); o.d2 = tree_from_below<D>(s.d2); o.d3 = tree_from_below<D>(s.d3);
+  o.rd = tree_from_below<D>(s.rd); o.rc = tree_from_below<D>(s.rc);
   return o;
 }
 template <int CTRL, int ROWS, int BANKS> __device__ __forceinline__ int dpp_zero(int v) {

@@ -1,5 +1,5 @@
 // Kernel instantiation lists (X-macros): one line per instantiation, X(R, DT, SEC, M, W, FULL, BCK).
-//   FULL == 1: no per-cell padding selects, valid only for N-1 in {64*W*M-1, 64*W*M}
+//   M = rows of the scalar system per lane (>= 2), W = waves per reach; FULL == 1: no per-row selects, valid only for N = 64*W*M
 //   BCK: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //        1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
 // fs_abi.hip builds its dispatch table from them; the fs_part_*.hip translation units instantiate them (compiled in
@@ -19,14 +19,12 @@ void fs_launch(const void *args, int B, hipStream_t st) {
 }
 
 #define FS_LIST_RECT(X, R, DT) \
-  X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 2, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 16, 4, 0, 0) \
-  X(R, DT, FS_SEC_RECT_UNIFORM, 1, 1, 0, 1) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, 1) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, 1) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, 1) \
@@ -48,7 +46,6 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(R, DT, FS_SEC_RECT_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
 
 #define FS_LIST_TRAP(X, R, DT) \
-  X(R, DT, FS_SEC_TRAP_UNIFORM, 1, 1, 0, 0) \
   X(R, DT, FS_SEC_TRAP_UNIFORM, 2, 1, 0, 0) \
   X(R, DT, FS_SEC_TRAP_UNIFORM, 4, 1, 0, 0) \
   X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, 0) \
@@ -58,13 +55,11 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(R, DT, FS_SEC_TRAP_UNIFORM, 8, 1, 0, FS_BCK(FS_BC_RATING_POWER))
 
 #define FS_LIST_TABLE(X, R, DT) \
-  X(R, DT, FS_SEC_TABLE, 1, 1, 0, 0) \
   X(R, DT, FS_SEC_TABLE, 2, 1, 0, 0) \
   X(R, DT, FS_SEC_TABLE, 4, 1, 0, 0) \
   X(R, DT, FS_SEC_TABLE, 8, 1, 0, 0) \
   X(R, DT, FS_SEC_TABLE, 8, 2, 0, 0) \
   X(R, DT, FS_SEC_TABLE, 8, 4, 0, 0) \
-  X(R, DT, FS_SEC_TABLE, 1, 1, 0, -1) \
   X(R, DT, FS_SEC_TABLE, 2, 1, 0, -1) \
   X(R, DT, FS_SEC_TABLE, 4, 1, 0, -1) \
   X(R, DT, FS_SEC_TABLE, 8, 1, 0, -1) \
@@ -73,11 +68,9 @@ void fs_launch(const void *args, int B, hipStream_t st) {
 
 // polyline sections: fp64 only, a few shapes (the section walk dominates, not the elimination)
 #define FS_LIST_IRREGULAR(X) \
-  X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, 0) \
-  X(double, FS_F64, FS_SEC_IRREGULAR, 1, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)

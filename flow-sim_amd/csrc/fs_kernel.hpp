@@ -8,20 +8,20 @@
 //     registers for the whole launch (M+1 nodes, the last one shared with lane t+1);
 //   * the level-(k) halves of the 4-point Preissmann stencil (preissmann.py:899-910) are reduced
 //     to 4 constants per cell, kept in LDS, written once per level, read once per iteration;
-//   * the 2x2-block banded Jacobian is never materialised: each cell's 8 entries
-//     (preissmann.py:407-733) are folded straight into the lane's running segment
-//     (fs_device.hpp); the 64*W lane segments are reduced by a log-depth tree - DPP moves inside a
-//     wave, one LDS mailbox and one barrier across waves - the two boundary rows close the system,
-//     the separators come back down (every lane tracks both ends of its group and reads the group's
-//     record from LDS: no cross-lane traffic) and each lane back-substitutes its chunk;
+//   * the 2x2-block banded Jacobian is never materialised: in characteristic-like unknowns the continuity rows
+//     are substitutions and the momentum rows one scalar tridiagonal system (fs_device.hpp); each cell's entries
+//     (preissmann.py:407-733) are folded straight into the lane's running segment; the 64*W lane segments are
+//     reduced by a log-depth tree - DPP moves inside a wave, one LDS mailbox and one barrier across waves - the
+//     upstream boundary row closes the system, the separators come back down (every lane carries two numbers of
+//     its group and reads the group's record from LDS: no cross-lane traffic) and each lane back-substitutes;
 //   * HBM is read once per launch and written at its last level (every level only into an optional
 //     history): the accepted iterate of level k (preissmann.py:166-177; SURVEY F2: the pre-update
 //     iterate) seeds the level constants of k+1 straight from registers.  Boundary hydrographs and
 //     iteration counts go to small per-level tables.
 //
-// Template parameters: R = float|double, SEC = FS_SEC_*, M = cells per lane, W = waves per reach,
-// RAGGED = false promises N-1 in {64*W*M - 1, 64*W*M}: then only the very last cell of a lane can be
-// padding and the per-cell padding selects (and their 64-bit lane masks) disappear;
+// Template parameters: R = float|double, SEC = FS_SEC_*, M = rows per lane (>= 2), W = waves per reach,
+// RAGGED = false promises N = 64*W*M: then every row is a cell except the very last one (the downstream
+// boundary row) and the per-row selects (and their 64-bit lane masks) disappear;
 // BCK (boundary-kind class the kernel is compiled for): -1 = any kinds, 0 = any but FS_BC_STORAGE_CURVE (the row
 // evaluation switches at run time),
 // 1 = RECT_UNIFORM with bc_is_light() kinds on both ends (closed-form rows, parameters in LDS), 2 + k = flow
@@ -82,6 +82,12 @@
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
+#ifndef FS_PRIME
+#define FS_PRIME 0       // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
+#endif                   // through it: one code instance whatever the compiler does; flagship -3 %: 390 registers instead of 322);
+                         // 0: from a second instance of that code ahead of the loop.  Every multiply-add of the level constants and of the
+                         // uniform-geometry node terms is written as an explicit fma, so the two instances cannot be contracted
+                         // differently and chunked stepping / a restart gives the bits of one launch there too
 
 namespace fs {
 
@@ -148,6 +154,7 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   }
   __device__ __forceinline__ R bed_step(int) const { return dz; }   // bed(node+1) - bed(node)
   __device__ __forceinline__ R terms_T() const { return b; }
+  __device__ __forceinline__ R rT_const() const { return rb; }
   // distance-weighted interpolation between the two end sections (cross_section.py:887-900)
   __device__ __forceinline__ R bed(int node) const {
     const R w2 = R(node) * inv_nm1;
@@ -186,6 +193,7 @@ template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   }
   __device__ __forceinline__ R bed_step(int) const { return dz; }
   __device__ __forceinline__ R terms_T() const { return R(0); }      // unused (kConstT == false)
+  __device__ __forceinline__ R rT_const() const { return R(0); }
   __device__ __forceinline__ R bed(int node) const {
     const R w2 = R(node) * inv_nm1;
     return z_us * (R(1) - w2) + z_ds * w2;
@@ -216,6 +224,7 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
     n_over = has_over ? a.n_override[reach] : R(0);
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }      // unused (kConstT == false)
+  __device__ __forceinline__ R rT_const() const { return R(0); }
   __device__ __forceinline__ R bed_step(int node) const {
     return tab[(size_t)FS_GEO_Z_BED * N + min(node + 1, N - 1)] - tab[(size_t)FS_GEO_Z_BED * N + min(node, N - 1)];
   }
@@ -256,6 +265,7 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     px = a.poly_x; pz = a.poly_z; plim = a.poly_lim; pn = a.poly_n;
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }
+  __device__ __forceinline__ R rT_const() const { return R(0); }
   __device__ __forceinline__ R bed_step(int node) const { return tb.bed_step(node); }
   __device__ __forceinline__ R bed(int node) const { return tb.bed(node); }
   __device__ __forceinline__ SecParams<R> section(int node) const { return tb.section(node); }
@@ -291,10 +301,6 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
 };
 
 // LDS carve-up for one reach
-// W == 8 (512 threads, N up to 4097 at M = 8): the level-0 records of the in-wave tree stay in
-// registers (20 per lane) so that the LDS slots of levels 1..5 (31 per wave) fit next to kc.
-template <int W> struct TreeCfg { static constexpr bool kL0Regs = (W >= 8); static constexpr int kSlots = kL0Regs ? 32 : 64; };
-
 // (A, Se, Q/A) of the nodes as the last fold saw them (kSaveTerms); an empty base otherwise
 template <typename R, int M, int T, bool SAVE> struct SavedTerms { R nt[3][M + 1][T]; };
 template <typename R, int M, int T> struct SavedTerms<R, M, T, false> {};
@@ -302,20 +308,18 @@ template <typename R, int M, int T> struct SavedTerms<R, M, T, false> {};
 template <typename R, int M, int W, bool SAVE> struct Smem : SavedTerms<R, M, 64 * W, SAVE> {
   static constexpr int T = 64 * W;
   R kc[4][M][T];           // per-cell level-k constants, lane-minor (conflict-free ds_read_b64)
-  R tree[W][10][TreeCfg<W>::kSlots];   // per-wave spill slots of the in-wave tree
-  R xseg[2][W][10];        // wave segments, double-buffered by iteration parity
-  R xbc[2][8];             // boundary rows: U(dh,dq,res) D(dh,dq,res)
+  R tree[W][4][64];        // per-wave records of the in-wave tree (Elim: 4 numbers per merge, 63 merges)
+  R xseg[2][W][8];         // wave segments, double-buffered by iteration parity
+  R xbc[2][4];             // upstream boundary row on (p_0, m_0): aU, bU, rU
   R bcp[2][FS_BC_MAX_PARAMS];   // this reach's boundary parameters (fixed-size kinds), read every Newton iteration
   R xnorm[2][W];
   int32_t xflag[2];
 };
 
-// What back-substitution needs for an interior node j of a lane's chunk: the M-like row of the
-// running segment [first node .. j] (sm, pm, qm), pre-scaled by 1/det of the pivot block.  The
-// continuity row of cell j that completes the block (T_j/(2dt), -+theta/dx and its residual) is
-// recomputed from the still un-updated state when the top width is constant (kConstT), else its
-// residual is kept in qc.
-template <typename R> struct LocalElim { Parked<R> rs0, rs1, rk, rq, qc; };   // lives in AGPRs
+// What back-substitution needs for row j of a lane's chunk: m_{j-1} = R3 - R1 p_a - R2 m_j (the running down row at the
+// time row j was added, divided by its pivot).  The continuity residual rc_{j-1} that turns m_{j-1} into p_j is
+// recomputed from the still un-updated state when the top width is constant (kConstT), else it is kept in qc.
+template <typename R> struct LocalElim { Parked<R> R1, R2, R3, qc; };
 
 // Minimum number of waves per SIMD a kernel is compiled for: caps its registers at 512 / n.  One wave per SIMD cannot
 // hide the latency of the in-wave tree, a second one is worth 20-80 % wherever the kernel fits 256 registers or nearly
@@ -331,10 +335,14 @@ template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() 
   return FS_WPE_W1;
 }
 
+// Rows of the scalar system (fs_device.hpp): row k is the momentum row of cell k for k < N-1, the downstream boundary row
+// for k = N-1 and an identity row (m_k = 0) beyond; lane t owns rows [t M, (t+1) M) and holds the nodes t M .. (t+1) M.
+// RAGGED = false promises N = 64 W M: every row is a cell but the very last one, which is the boundary row.
 // DIAG = false: no per-level history and no residual trace (batches created without FS_FLAG_HISTORY / FS_FLAG_TRACE): the
 // stores are never executed there, but compiled in they cost the flagship kernel 1.1 %
 template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true>
 __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
+  static_assert(M >= 2, "a lane's segment needs two rows (its up and its down row)");
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   // Short general-section kernels keep (A, Se, Q/A) of every node of the current fold in LDS: if the iterate is accepted they
@@ -354,10 +362,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     if (it_entry < 0) return;                 // this reach has closed the level: it waits for the others (whole workgroup)
   }
   const int N = a.N, NC = N - 1;
-  const int s0 = t * M;                       // first node / cell of this lane
-  const int tD = (NC - 1) / M;                // lane that owns the last real cell
-  const int jD = NC - tD * M;                 // local index (1..M) of node N-1 in that lane
-  constexpr int kJD0 = RAGGED ? 1 : (M > 1 ? M - 1 : 1);   // full chunks: jD is M-1 or M
+  const int s0 = t * M;                       // first node / row of this lane
+  const int tD = RAGGED ? NC / M : T - 1;     // lane that owns node N-1 and the downstream boundary row ...
+  const int jD = RAGGED ? NC - tD * M : M - 1;   // ... as its local node / row jD (0..M-1)
   const size_t base = (size_t)reach * N;
 
   Geo geo;
@@ -370,6 +377,13 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   R hth = R(0.5) * th;
   const R hthk = R(0.5) * (R(1) - th);
   R g = R(kG);
+  // scalings into the characteristic-like unknowns p = t dh + cq dQ, m = t dh - cq dQ (t = T/(2dt), fs_device.hpp):
+  // 1/(2t) = dt/T, 1/(2cq), and the quotient of the two time / space weights k = (1/(2dt)) / (2cq)
+  R i2c = R(0.5) / cq;
+  R kap = r2dt * i2c;
+  R dtcq = dt * cq;
+  R ghx = g * hth * i2c;                      // g (theta/2) / (2cq)
+  R ghdt = g * hth * dt;
 
   // ---- unknowns of this lane: nodes s0 .. s0+M (clamped copies beyond the last node) ----
   R h[M + 1], Q[M + 1];
@@ -379,14 +393,15 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   //   C = [sumA]/(2dt) + cq*dQ                 + kc0
   //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + g*(hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)
   // Node s0 + M is lane + 1's node s0 (both lanes hold bitwise equal copies of its unknowns): with one wave per reach the
-  // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding cell ever looks at
+  // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding row ever looks at
   // (and discards) unless the reach fills the wave exactly - then lane 63 evaluates its last node itself.
   constexpr bool kShareNode = FS_SHARE_NODE && W == 1 && !Geo::kConstT;
   auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) {
     auto rol = [](R v) { return dpp_mov<0x134>(v); };     // wave_rol:1
     NodeTerms<R> r;
     r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eA = rol(first.eA); r.eQ = rol(first.eQ); r.v = rol(first.v);
-    if (NC == 64 * M && lane == 63) r = geo.terms(N - 1, hM, QM);
+    r.rT = rol(first.rT);
+    if (NC >= 64 * M - 1 && lane == 63) r = geo.terms(min(s0 + M, N - 1), hM, QM);
     return r;
   };
   auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
@@ -397,10 +412,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     for (int c = 0; c < M; ++c) {
       const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
       const R sumA = L.A + Rn.A;
-      sm.kc[0][c][t] = -sumA * r2dt + cqk * (QQ[c + 1] - QQ[c]);
-      sm.kc[1][c][t] = -(QQ[c + 1] + QQ[c]) * r2dt + cqk * (QQ[c + 1] * Rn.v - QQ[c] * L.v);
+      // explicit fmas only (no a*b + c left to the compiler's choice: see FS_PRIME)
+      sm.kc[0][c][t] = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
+      sm.kc[1][c][t] = fma_(cqk, fma_(QQ[c + 1], Rn.v, -(QQ[c] * L.v)), -((QQ[c + 1] + QQ[c]) * r2dt));
       sm.kc[2][c][t] = hthk * sumA;
-      sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (L.Se + Rn.Se);
+      sm.kc[3][c][t] = fma_(cqk, geo.bed_step(s0 + c) + (hh[c + 1] - hh[c]), hthk * (L.Se + Rn.Se));
       L = Rn;
 #if FS_LEVEL_FENCE
       if ((c % FS_LEVEL_FENCE) == FS_LEVEL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
@@ -417,19 +433,24 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       for (int c = 0; c < M; ++c) {
         const R A1 = sm.nt[0][c + 1][t], Se1 = sm.nt[1][c + 1][t], v1 = sm.nt[2][c + 1][t];
         const R sumA = A0 + A1;
-        sm.kc[0][c][t] = -sumA * r2dt + cqk * (QQ[c + 1] - QQ[c]);
-        sm.kc[1][c][t] = -(QQ[c + 1] + QQ[c]) * r2dt + cqk * (QQ[c + 1] * v1 - QQ[c] * v0);
+        sm.kc[0][c][t] = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
+        sm.kc[1][c][t] = fma_(cqk, fma_(QQ[c + 1], v1, -(QQ[c] * v0)), -((QQ[c + 1] + QQ[c]) * r2dt));
         sm.kc[2][c][t] = hthk * sumA;
-        sm.kc[3][c][t] = cqk * (geo.bed_step(s0 + c) + (hh[c + 1] - hh[c])) + hthk * (Se0 + Se1);
+        sm.kc[3][c][t] = fma_(cqk, geo.bed_step(s0 + c) + (hh[c + 1] - hh[c]), hthk * (Se0 + Se1));
         A0 = A1; Se0 = Se1; v0 = v1;
       }
     }
   };
 
+  // The launch starts with a priming pass: (h, Q) hold the accepted state of the entry level and run through the
+  // acceptance block of the loop below once (level constants of the first level to solve, flow[k] of the storage row),
+  // then they are replaced by the Newton start vector.  The level constants of every level - the first one of a launch
+  // included - thus come from ONE instance of the code, and chunked stepping / a restart gives the bits of one launch.
+  constexpr bool kPrime = FS_PRIME;
 #pragma unroll
   for (int j = 0; j <= M; ++j) {
     const int node = min(s0 + j, N - 1);
-    h[j] = a.hg[base + node];  Q[j] = a.Qg[base + node];
+    h[j] = kPrime ? a.hk[base + node] : a.hg[base + node];  Q[j] = kPrime ? a.Qk[base + node] : a.Qg[base + node];
   }
   // per-lane base pointers: every later access is base + immediate offset
   R *const hk_p = a.hk + base + s0, *const Qk_p = a.Qk + base + s0;
@@ -457,11 +478,12 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(a.ds.kind);
   R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
+  bool primed = false;                        // (h, Q) hold the Newton vector (after the priming pass), not the entry state
   int parity = 0;
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
   __syncthreads();
 
-  {   // accepted state of the entry level -> 4 constants per cell in LDS (later levels: from registers, below)
+  if (!kPrime) {   // accepted state of the entry level -> 4 constants per cell in LDS (a second instance of that code)
     R hk[M + 1], Qk[M + 1];
 #pragma unroll
     for (int j = 0; j <= M; ++j) {
@@ -470,23 +492,32 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     }
     if (t == tD) {
 #pragma unroll
-      for (int j = kJD0; j <= M; ++j) if (j == jD) QoldD = Qk[j];
+      for (int j = RAGGED ? 0 : M - 1; j < M; ++j) if (j == jD) QoldD = Qk[j];
     }
     write_level_constants(hk, Qk);
+    primed = true;
   }
 #ifdef FS_STAMP
   unsigned long long stamp_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
-  for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
+  for (int step = kPrime ? -1 : 0; step < a.n_steps && status == FS_OK; ++step) {
+    int prime = kPrime && step < 0;             // the priming pass (opaque to the optimiser: one loop body, not two)
+    if (kPrime) asm volatile("" : "+s"(prime));
     const int level = a.level0 + step + 1;
-    if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
-    if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
+    if (!prime) {
+      if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
+      if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
+    }
     int it = kBudget ? it_entry : 0;
     int budget = (kBudget && a.iter_budget > 0) ? a.iter_budget : 0x7fffffff;
     bool converged = false;
     R Ynew = Yprev;
     while (!converged && status == FS_OK) {
+      R dh[M + 1], dQ[M + 1];                   // the update, pending until the acceptance block is through
+      if (prime) {
+        converged = true;
+      } else {
       if (kBudget && budget-- <= 0) break;
       ++it;
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
@@ -497,122 +528,129 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       // constants are Newton-loop invariants and would otherwise be hoisted into registers
       int kco = t;
       asm volatile("" : "+v"(kco));
-      // the same for the lane number the tree-slot addresses derive from: as loop invariants the 12 addresses
+      // the same for the lane number the tree-slot addresses derive from: as loop invariants the addresses
       // are hoisted and spilled to scratch, and every reload is a full memory round trip inside the tree
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const R *kcb = &sm.kc[0][0][0] + kco;
 
-      // ================= 1. local assembly + fold (registers only) =================
-      LocalElim<R> el[M > 1 ? M - 1 : 1];
-      R Tn[Geo::kConstT ? 1 : M + 1];           // top widths, only when they vary
-      Seg<R> seg;
-      R pf0 = R(0), pf1 = R(0);                // M-like row of the lane's first cell (left part)
+      // ================= 1. boundary rows (boundary.py:56-242) =================
+      // lane 0: the upstream row on (dh_0, dQ_0); the lane of node N-1: the downstream row, which is row N-1 of the
+      // scalar system and enters that lane's fold below like any other row
+      BCRow<R> Urow, Drow;
+      Drow.dh = R(1); Drow.dq = R(0); Drow.res = R(0);
       R nrm2 = R(0);
-      {
-        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
-        NodeTerms<R> Rlast;
-        if (kShareNode) Rlast = last_node_terms(L, h[M], Q[M]);
-        save_terms(0, L);
-        if (!Geo::kConstT) Tn[0] = L.T;
-        R kap = R(1);                      // the M-like row keeps the direction of cell 0's: pm = kap * (pf0, pf1)
-#pragma unroll
-        for (int c = 0; c < M; ++c) {
-          const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
-          const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
-          save_terms(c + 1, Rn);
-          if (!Geo::kConstT) Tn[c + 1] = Rn.T;
-          Seg<R> cell;
-          {
-            // identity padding d_{i+1} = d_i beyond the last cell
-            const bool real = (RAGGED || c == M - 1) ? (s0 + c < NC) : true;
-            const R sumA = L.A + Rn.A;
-            const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + k0;                            // :220-249
-            const R avgA = hth * sumA + k2;
-            const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + k3;
-            const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + k1 +
-                           g * avgA * S;                                                     // :251-301
-            nrm2 += real ? Cres * Cres + Mres * Mres : R(0);
-            const R gA = g * avgA, gS = g * hth * S;
-            cell.pc0 = real ? L.T * r2dt : R(1);   cell.pc1 = real ? -cq : R(0);             // :431-447, :476-491
-            cell.sc0 = real ? Rn.T * r2dt : R(-1); cell.sc1 = real ? cq : R(0);              // :407-422, :456-471
-            cell.qc = real ? -Cres : R(0);
-            cell.pm0 = real ? cq * L.v * L.v * L.T + gA * (hth * L.eA - cq) + gS * L.T : R(0);        // :558-612
-            cell.pm1 = real ? r2dt - cq * R(2) * L.v + gA * hth * L.eQ : R(1);                         // :677-733
-            cell.sm0 = real ? -cq * Rn.v * Rn.v * Rn.T + gA * (hth * Rn.eA + cq) + gS * Rn.T : R(0);  // :496-550
-            cell.sm1 = real ? r2dt + cq * R(2) * Rn.v + gA * hth * Rn.eQ : R(-1);                      // :619-675
-            cell.qm = real ? -Mres : R(0);
-          }
-          if (c == 0) {
-            seg = cell;
-            pf0 = cell.pm0; pf1 = cell.pm1;
-          } else {
-            // merge(seg, cell) keeping only what the local back-substitution reads.  The merged M-like row's
-            // left part is always a multiple of cell 0's (o.pm = -ga * seg.pm): only the factor kap is carried
-            // and recorded, which is one value per node less to park and one multiplication less per merge.
-            const R det = pivot_det(seg.sm0, seg.sm1, cell.pc0, cell.pc1);
-            const R r = frcp(det);
-            LocalElim<R> &e = el[c - 1];
-            const R w21 = r * seg.sm0, rs1 = r * seg.sm1;
-            e.rs0.put(w21); e.rs1.put(rs1); e.rk.put(r * kap); e.rq.put(r * seg.qm);
-            if (!Geo::kConstT) e.qc.put(cell.qc);
-            const R w10 = cell.pc1 * r, w11 = -cell.pc0 * r, w20 = -rs1;
-            const R al = seg.sc0 * w10 + seg.sc1 * w11, be = seg.sc0 * w20 + seg.sc1 * w21;
-            const R ga = cell.pm0 * w10 + cell.pm1 * w11, ep = cell.pm0 * w20 + cell.pm1 * w21;
-            const R ak = al * kap;
-            Seg<R> o;
-            o.pc0 = seg.pc0 - ak * pf0;     o.pc1 = seg.pc1 - ak * pf1;
-            o.sc0 = -be * cell.sc0;         o.sc1 = -be * cell.sc1;
-            o.qc = seg.qc - al * seg.qm - be * cell.qc;
-            kap = -ga * kap;
-            o.pm0 = R(0);                   o.pm1 = R(0);          // materialised after the last cell
-            o.sm0 = cell.sm0 - ep * cell.sc0; o.sm1 = cell.sm1 - ep * cell.sc1;
-            o.qm = cell.qm - ga * seg.qm - ep * cell.qc;
-            seg = o;
-          }
-#if FS_PIN_SEG
-          // the running segment must exist here: keeps cell c's merge inside cell c's scheduling region
-          // (otherwise the 15 merges sink below the last fence and every cell's coefficients are parked)
-          // (long chunks only: with M <= 4 the cells' node terms interleave profitably, measured on C4)
-          if (M >= 8)
-            asm volatile("" :: "v"(seg.pc0), "v"(seg.pc1), "v"(seg.sc0), "v"(seg.sc1), "v"(seg.qc),
-                               "v"(kap), "v"(seg.sm0), "v"(seg.sm1), "v"(seg.qm));
-#endif
-          L = Rn;
-#if FS_CELL_FENCE
-          if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
-        }
-        seg.pm0 = kap * pf0; seg.pm1 = kap * pf1;
-      }
-
-      FS_T(0);
-      // ================= 2. boundary rows =================
       if (t == 0) {
         R dummy; int flag = 0;
-        const BCRow<R> U = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
-        sm.xbc[parity][0] = U.dh; sm.xbc[parity][1] = U.dq; sm.xbc[parity][2] = U.res;
-        nrm2 += U.res * U.res;
+        Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+        nrm2 = Urow.res * Urow.res;
       }
       if (t == tD) {
         R hD = h[0], QD = Q[0];
         int flag = 0;
 #pragma unroll
-        for (int j = kJD0; j <= M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        const BCRow<R> Dn = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
-        sm.xbc[parity][3] = Dn.dh; sm.xbc[parity][4] = Dn.dq; sm.xbc[parity][5] = Dn.res;
-        nrm2 += Dn.res * Dn.res;
+        for (int j = RAGGED ? 1 : M - 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+        Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+        nrm2 += Drow.res * Drow.res;
         if (flag) sm.xflag[parity] = flag;
       }
-
       FS_T(1);
+
+      // ================= 2. local assembly + fold (registers only) =================
+      LocalElim<R> el[M - 1];
+      R iTn[Geo::kConstT ? 1 : M + 1];           // dt / T = 1/(2t) of the nodes, only when the top width varies
+      Seg<R> seg;                                 // running rows of the lane's segment
+      seg.u1 = R(0); seg.u3 = R(-1); seg.ru = R(0);
+      R upU1 = R(0), upU3 = R(0), upRu = R(0);    // the lane's finished up row, kept for the way back
+      R rcLast = R(0);                            // rc of the lane's last row (links node M: p_M = rc - m_{M-1})
+      {
+        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+        NodeTerms<R> Rlast;
+        if (kShareNode) Rlast = last_node_terms(L, h[M], Q[M]);
+        save_terms(0, L);
+        R i2tL = dt * L.rT;
+        if (!Geo::kConstT) iTn[0] = i2tL;
+        if (t == 0) {                           // upstream row on (p_0, m_0): aU p_0 + bU m_0 = -res
+          const R x = Urow.dh * i2tL, y = Urow.dq * i2c;
+          sm.xbc[parity][0] = x + y; sm.xbc[parity][1] = x - y; sm.xbc[parity][2] = -Urow.res;
+        }
+        R rcPrev = R(0);
+#pragma unroll
+        for (int c = 0; c < M; ++c) {
+          const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
+          const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+          save_terms(c + 1, Rn);
+          const R i2tR = dt * Rn.rT;
+          if (!Geo::kConstT) iTn[c + 1] = i2tR;
+          Row<R> row;
+          {
+            const R sumA = L.A + Rn.A;
+            const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + k0;                            // :220-249
+            const R avgA = hth * sumA + k2;
+            const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + k3;
+            const R gA = g * avgA;
+            const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + k1 + gA * S;   // :251-301
+            // momentum entries (preissmann.py:496-733) scaled by 1/(2t) of their node (dh) and 1/(2cq) (dQ):
+            //   X0 = pm0 dt/T0, Y0 = pm1/(2cq), X1 = sm0 dt/T1, Y1 = sm1/(2cq)
+            const R gAdt = gA * dt, gAx = avgA * ghx, sdt = ghdt * S;
+            const R X0 = fma_(gAdt, L.rT * fma_(hth, L.eA, -cq), fma_(dtcq, L.v * L.v, sdt));       // :558-612
+            const R X1 = fma_(gAdt, Rn.rT * fma_(hth, Rn.eA, cq), fma_(-dtcq, Rn.v * Rn.v, sdt));    // :496-550
+            const R Y0 = fma_(gAx, L.eQ, kap - L.v);                                                 // :677-733
+            const R Y1 = fma_(gAx, Rn.eQ, kap + Rn.v);                                               // :619-675
+            const R ga = X1 + Y1;
+            row.al = X0 + Y0; row.D = (X0 - Y0) - ga; row.de = X1 - Y1;
+            row.rho0 = fma_(ga, Cres, -Mres);             // qm - ga rc with qm = -Mres, rc = -Cres
+            row.rc = -Cres;
+            R r2 = fma_(Cres, Cres, Mres * Mres);
+            // rows beyond the cells: the downstream boundary row (on p and m of node N-1), then identity rows
+            if (RAGGED || c == M - 1) {
+              const int k = s0 + c;
+              const bool cell = RAGGED ? (k < NC) : (t != T - 1);
+              const bool bcr = RAGGED ? (k == NC) : true;
+              if (!cell) {
+                const R x = Drow.dh * i2tL, y = Drow.dq * i2c;
+                row.al = bcr ? x + y : R(0); row.D = bcr ? x - y : R(1); row.de = R(0);
+                row.rho0 = bcr ? -Drow.res : R(0); row.rc = R(0);
+                r2 = R(0);
+              }
+            }
+            nrm2 += r2;
+          }
+          if (c == 0) {
+            seg.d1 = row.al; seg.d2 = row.D; seg.d3 = row.de; seg.rd = row.rho0;
+          } else {
+            // forward elimination of m_{c-1} (pivot: the running down row), the up row follows (fs_device.hpp)
+            const R r = frcp(seg.d2);
+            const R R1 = seg.d1 * r, R2 = seg.d3 * r, R3 = seg.rd * r;
+            LocalElim<R> &e = el[c - 1];
+            e.R1.put(R1); e.R2.put(R2); e.R3.put(R3);
+            if (!Geo::kConstT) e.qc.put(rcPrev);
+            const R rho = fma_(-row.al, rcPrev, row.rho0);
+            seg.d1 = row.al * R1; seg.d2 = fma_(row.al, R2, row.D); seg.d3 = row.de; seg.rd = fma_(row.al, R3, rho);
+            seg.u1 = fma_(-seg.u3, R1, seg.u1); seg.ru = fma_(-seg.u3, R3, seg.ru); seg.u3 = -(seg.u3 * R2);
+          }
+          rcPrev = row.rc;
+#if FS_PIN_SEG
+          // the running rows must exist here: keeps row c's elimination inside cell c's scheduling region
+          // (otherwise the eliminations sink below the last fence and every cell's coefficients are parked)
+          // (long chunks only: with M <= 4 the cells' node terms interleave profitably, measured on C4)
+          if (M >= 8)
+            asm volatile("" :: "v"(seg.u1), "v"(seg.u3), "v"(seg.ru), "v"(seg.d1), "v"(seg.d2), "v"(seg.d3), "v"(seg.rd), "v"(rcPrev));
+#endif
+          L = Rn; i2tL = i2tR;
+#if FS_CELL_FENCE
+          if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        seg.rc = rcPrev; rcLast = rcPrev;
+        upU1 = seg.u1; upU3 = seg.u3; upRu = seg.ru;
+      }
+
+      FS_T(0);
 #if FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);   // phases are not interleaved: it only costs registers (measured around the down-sweep: +5 %)
 #endif
       // ================= 3. in-wave tree (up-sweep) =================
-      constexpr bool L0R = TreeCfg<W>::kL0Regs;
-      constexpr int TS = TreeCfg<W>::kSlots;
-      Elim<R> e_l0;                     // level-0 record (odd lanes), only when L0R
       auto up_level = [&](auto lc) {
         constexpr int l = decltype(lc)::value;
         constexpr int d = 1 << l;
@@ -620,14 +658,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         Seg<R> mg; Elim<R> e;
         merge(left, seg, mg, e);
         if ((lane & (2 * d - 1)) == (2 * d - 1)) {
-          if (L0R && l == 0) {
-            e_l0 = e;
-          } else {
-            const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
-            R *p = &sm.tree[wave][0][slot];
-            p[0 * TS] = e.w10; p[1 * TS] = e.w11; p[2 * TS] = e.w20; p[3 * TS] = e.w21; p[4 * TS] = e.pm0;
-            p[5 * TS] = e.pm1; p[6 * TS] = e.qm;  p[7 * TS] = e.sc0; p[8 * TS] = e.sc1; p[9 * TS] = e.qc;
-          }
+          const int slot = (64 - (64 >> l)) + (ln >> (l + 1));
+          R *p = &sm.tree[wave][0][slot];
+          p[0 * 64] = e.A1; p[1 * 64] = e.A2; p[2 * 64] = e.A3; p[3 * 64] = e.rc;
         }
         seg = mg;      // in every lane: a lane that does not survive this level is not read again (no select, no branch around the merge)
       };
@@ -637,60 +670,59 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #if FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);
 #endif
-#if FS_PHASE_FENCE & 4
-      asm volatile("" : "+v"(seg.pc0), "+v"(seg.pc1), "+v"(seg.sc0), "+v"(seg.sc1), "+v"(seg.qc));
-      asm volatile("" : "+v"(seg.pm0), "+v"(seg.pm1), "+v"(seg.sm0), "+v"(seg.sm1), "+v"(seg.qm));
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       nrm2 = wave_sum(nrm2);
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
-        p[0] = seg.pc0; p[1] = seg.pc1; p[2] = seg.sc0; p[3] = seg.sc1; p[4] = seg.qc;
-        p[5] = seg.pm0; p[6] = seg.pm1; p[7] = seg.sm0; p[8] = seg.sm1; p[9] = seg.qm;
+        p[0] = seg.u1; p[1] = seg.u3; p[2] = seg.ru; p[3] = seg.d1; p[4] = seg.d2; p[5] = seg.d3; p[6] = seg.rd; p[7] = seg.rc;
         sm.xnorm[parity][wave] = nrm2;
       }
       FS_T(2);
       __syncthreads();
       FS_T(3);
 
-      // ================= 4. across waves: fold, close with the boundary rows, unfold =================
+      // ================= 4. across waves: fold, close with the upstream row, unfold =================
       R tot = R(0);
-      R bL0, bL1, bR0, bR1;          // updates at the first / last node of this wave's span
+      R pL, mR;                        // p of this wave's first row, m of its last one
+      R mAw = R(0), mBw = R(0);        // m of this wave's first row / of the next wave's first row (shared nodes, below)
       {
         // pairwise tree over the W wave segments (depth log2 W instead of a serial chain of W-1 merges;
-        // the two merges of a level are independent and overlap)
-        Seg<R> sw[W];
+        // the two merges of a level are independent and overlap); every thread does all of it
+        Seg<R> sw[W], sw0[W];
         Elim<R> we[W > 1 ? W - 1 : 1];
 #pragma unroll
         for (int w = 0; w < W; ++w) {
           const R *p = sm.xseg[parity][w];
-          sw[w].pc0 = p[0]; sw[w].pc1 = p[1]; sw[w].sc0 = p[2]; sw[w].sc1 = p[3]; sw[w].qc = p[4];
-          sw[w].pm0 = p[5]; sw[w].pm1 = p[6]; sw[w].sm0 = p[7]; sw[w].sm1 = p[8]; sw[w].qm = p[9];
+          sw[w].u1 = p[0]; sw[w].u3 = p[1]; sw[w].ru = p[2]; sw[w].d1 = p[3]; sw[w].d2 = p[4]; sw[w].d3 = p[5];
+          sw[w].rd = p[6]; sw[w].rc = p[7];
+          sw0[w] = sw[w];
           tot += sm.xnorm[parity][w];
         }
 #pragma unroll
         for (int st = 1; st < W; st *= 2)
 #pragma unroll
           for (int i = 0; i + st < W; i += 2 * st) merge(sw[i], sw[i + st], sw[i], we[i + st - 1]);
-        BCRow<R> U, Dn;
-        U.dh = sm.xbc[parity][0]; U.dq = sm.xbc[parity][1]; U.res = sm.xbc[parity][2];
-        Dn.dh = sm.xbc[parity][3]; Dn.dq = sm.xbc[parity][4]; Dn.res = sm.xbc[parity][5];
-        R bnd[W + 1][2];
-        close_system(sw[0], U, Dn, bnd[0][0], bnd[0][1], bnd[W][0], bnd[W][1]);
+        R pw[W], mw[W], p0, m0, ml;      // pw[w], mw[w]: the two numbers of wave w (valid for the group heads while unfolding)
+        close_root(sw[0], sm.xbc[parity][0], sm.xbc[parity][1], sm.xbc[parity][2], p0, m0, ml);
+        pw[0] = p0; mw[0] = ml;
 #pragma unroll
         for (int st = W / 2; st >= 1; st /= 2)
 #pragma unroll
-          for (int i = 0; i + st < W; i += 2 * st)
-            back(we[i + st - 1], bnd[i][0], bnd[i][1], bnd[i + 2 * st][0], bnd[i + 2 * st][1], bnd[i + st][0], bnd[i + st][1]);
-        bL0 = bnd[0][0]; bL1 = bnd[0][1]; bR0 = bnd[1][0]; bR1 = bnd[1][1];
+          for (int i = 0; i + st < W; i += 2 * st) {
+            const Elim<R> &e = we[i + st - 1];
+            const R sep = separator(e, pw[i], mw[i]);
+            pw[i + st] = e.rc - sep; mw[i + st] = mw[i]; mw[i] = sep;
+          }
+        // m of every wave's first row from its own up row: the node there is shared with the wave before, and both
+        // copies must move by the same bits
+        R ma[W + 1];
+#pragma unroll
+        for (int w = 0; w < W; ++w) ma[w] = fma_(-sw0[w].u1, pw[w], fma_(-sw0[w].u3, mw[w], sw0[w].ru));
+        ma[W] = R(0);
+        pL = pw[0]; mR = mw[0]; mAw = ma[0]; mBw = ma[1];
 #pragma unroll
         for (int w = 1; w < W; ++w)
-          if (wave == w) { bL0 = bnd[w][0]; bL1 = bnd[w][1]; bR0 = bnd[w + 1][0]; bR1 = bnd[w + 1][1]; }
+          if (wave == w) { pL = pw[w]; mR = mw[w]; mAw = ma[w]; mBw = ma[w + 1]; }
       }
-#if FS_PHASE_FENCE & 2
-      asm volatile("" : "+v"(bL0), "+v"(bL1), "+v"(bR0), "+v"(bR1), "+v"(tot));
-      __builtin_amdgcn_sched_barrier(0);
-#endif
       FS_T(4);
       const R err = sqrt_(tot);                                        // utility.py:20-22
       if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
@@ -700,41 +732,28 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
 
       FS_T(5);
-      // ================= 6. separators down the tree, local back-substitution, update ============
-      // Every lane carries the updates (aL, aR) at the two ends of the group of 2^(l+1) lanes it belongs
-      // to at the current level.  The group's elimination record is one LDS slot that all its lanes read
-      // (a broadcast read), each lane recovers the group's middle separator itself and keeps it as its
-      // new right end (lower half of the group) or left end (upper half): no cross-lane traffic and a
-      // dependent chain of four fp64 operations per level.
-      R aL0 = bL0, aL1 = bL1, aR0 = bR0, aR1 = bR1;
+      // ================= 5. separators down the tree, local back-substitution ============
+      // Every lane carries two numbers of the group of 2^(l+1) lanes it belongs to at the current level: the p of the
+      // group's first row and the m of its last one.  The group's record is one LDS slot that all its lanes read (a
+      // broadcast read); each lane recovers the separator itself and keeps it as its new right number (lower half) or
+      // turns it into its new left one (upper half): no cross-lane traffic, two dependent fp64 operations per level.
       auto load_rec = [&](auto lc) {
         constexpr int l = decltype(lc)::value;
         Elim<R> e;
-        if (L0R && l == 0) {
-          // level-0 records live in the odd lanes' registers: both lanes of a pair take the odd lane's copy
-          auto pair = [](R v) { return dpp_mov<0xF5>(v); };     // quad_perm:[1,1,3,3]
-          e.w10 = pair(e_l0.w10); e.w11 = pair(e_l0.w11); e.w20 = pair(e_l0.w20); e.w21 = pair(e_l0.w21);
-          e.pm0 = pair(e_l0.pm0); e.pm1 = pair(e_l0.pm1); e.qm = pair(e_l0.qm);
-          e.sc0 = pair(e_l0.sc0); e.sc1 = pair(e_l0.sc1); e.qc = pair(e_l0.qc);
-        } else {
-          const int slot = (L0R ? (32 - (64 >> l)) : (64 - (64 >> l))) + (ln >> (l + 1));
-          const R *p = &sm.tree[wave][0][slot];
-          e.w10 = p[0 * TS]; e.w11 = p[1 * TS]; e.w20 = p[2 * TS]; e.w21 = p[3 * TS]; e.pm0 = p[4 * TS];
-          e.pm1 = p[5 * TS]; e.qm = p[6 * TS];  e.sc0 = p[7 * TS]; e.sc1 = p[8 * TS]; e.qc = p[9 * TS];
-        }
+        const int slot = (64 - (64 >> l)) + (ln >> (l + 1));
+        const R *p = &sm.tree[wave][0][slot];
+        e.A1 = p[0 * 64]; e.A2 = p[1 * 64]; e.A3 = p[2 * 64]; e.rc = p[3 * 64];
         return e;
       };
       auto down_level = [&](auto lc, const Elim<R> &e) {
         constexpr int l = decltype(lc)::value;
-        R m0, m1;
-        back(e, aL0, aL1, aR0, aR1, m0, m1);
+        const R sep = separator(e, pL, mR);
         const bool upper = ((lane >> l) & 1) != 0;
-        aL0 = upper ? m0 : aL0; aL1 = upper ? m1 : aL1;
-        aR0 = upper ? aR0 : m0; aR1 = upper ? aR1 : m1;
+        pL = upper ? e.rc - sep : pL;
+        mR = upper ? mR : sep;
       };
       {
-        // records are requested exactly one level ahead (the memory clobbers keep the compiler from
-        // requesting all six up front, which costs 120 registers and sends the kernel to scratch)
+        // records are requested one level ahead (the memory clobbers keep the compiler from requesting all six up front)
         using I5 = std::integral_constant<int, 5>; using I4 = std::integral_constant<int, 4>;
         using I3 = std::integral_constant<int, 3>; using I2 = std::integral_constant<int, 2>;
         using I1 = std::integral_constant<int, 1>; using I0 = std::integral_constant<int, 0>;
@@ -755,15 +774,18 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         asm volatile("" ::: "memory");
         down_level(I1{}, r1);
         down_level(I0{}, r0);
-        asm volatile("" : "+v"(aL0), "+v"(aL1), "+v"(aR0), "+v"(aR1));
+        asm volatile("" : "+v"(pL), "+v"(mR));
         __builtin_amdgcn_sched_barrier(0);
       }
-      const R dR0 = aR0, dR1 = aR1, dL0 = aL0, dL1 = aL1;
+      // m of the lane's first row from its up row; a wave's first lane takes the number the cross-wave step computed, so
+      // that the last lane of the wave before (which gets the same number) moves its copy of the shared node identically
+      R mA = fma_(-upU1, pL, fma_(-upU3, mR, upRu));
+      if (W > 1 && lane == 0) mA = mAw;
+      R mB = dpp_mov<0x134>(mA);                // wave_rol:1 - m of the next lane's first row = this lane's node M
+      if (lane == 63) mB = mBw;
 
       // The update is kept pending in dh/dQ (they take the registers the elimination records free up):
       // the accepted iterate must still be intact for the level-constant pass below.
-      R dh[M + 1], dQ[M + 1];
-      dh[M] = dR0; dQ[M] = dR1; dh[0] = dL0; dQ[0] = dL1;
       if (Geo::kConstT && FS_LAUNDER_BACK) {
         // The continuity residuals are recomputed below on purpose (one value per node less to keep
         // across the solve).  Hide the operands so that common-subexpression elimination does not
@@ -774,28 +796,30 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         for (int j = 0; j <= M; ++j) asm volatile("" : "+v"(h[j]), "+v"(Q[j]));
       }
       {
-        R n0 = dR0, n1 = dR1;
-        const R pfL = pf0 * dL0 + pf1 * dL1;          // (first cell's M-like row) . (update at the lane's first node)
+        const R i2tc = dt * geo.rT_const();
+        auto i2t_of = [&](int j) { return Geo::kConstT ? i2tc : iTn[j]; };
+        // rc of row j for the link p_{j+1} = rc_j - m_j: minus the continuity residual of cell j, 0 beyond the cells
+        auto rc_of = [&](int j) {
+          if (Geo::kConstT) {
+            const R v = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
+            return (RAGGED && s0 + j >= NC) ? R(0) : v;
+          }
+          return j + 1 < M ? el[j].qc.get() : rcLast;
+        };
+        R mj = mR;                                  // m of row M-1
+        {
+          const R pM = rc_of(M - 1) - mR;          // node M: p from this lane's last row, m from the next lane
+          dh[M] = (pM + mB) * i2t_of(M); dQ[M] = (pM - mB) * i2c;
+        }
 #pragma unroll
         for (int j = M - 1; j >= 1; --j) {
-          const LocalElim<R> &e = el[j - 1];
-          // pivot block rows: (sm0, sm1) and the continuity row of cell j: (T_j/(2dt), -cq | T_{j+1}/(2dt), cq)
-          const bool real = (RAGGED || j == M - 1) ? (s0 + j < NC) : true;   // else identity padding
-          R c0, b0, qc;
-          if (Geo::kConstT) {
-            c0 = geo.terms_T() * r2dt; b0 = c0;
-            qc = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
-          } else {
-            c0 = Tn[j] * r2dt; b0 = Tn[j + 1] * r2dt; qc = e.qc.get();
-          }
-          const R c1 = real ? -cq : R(0), b1 = real ? cq : R(0);
-          if (!real) { c0 = R(1); b0 = R(-1); qc = R(0); }
-          const R rsig = e.rq.get() - e.rk.get() * pfL;
-          const R tau = qc - (b0 * n0 + b1 * n1);
-          n0 = c1 * rsig - e.rs1.get() * tau;
-          n1 = e.rs0.get() * tau - c0 * rsig;
-          dh[j] = n0; dQ[j] = n1;
+          // m_{j-1} = R3 - R1 p_a - R2 m_j ; row 0's m comes from the up row (mA)
+          const R mprev = j == 1 ? mA : fma_(-el[j - 1].R2.get(), mj, fma_(-el[j - 1].R1.get(), pL, el[j - 1].R3.get()));
+          const R pj = rc_of(j - 1) - mprev;
+          dh[j] = (pj + mj) * i2t_of(j); dQ[j] = (pj - mj) * i2c;
+          mj = mprev;
         }
+        dh[0] = (pL + mA) * i2t_of(0); dQ[0] = (pL - mA) * i2c;
       }
       FS_T(6);
 #if FS_PHASE_FENCE & 8
@@ -805,15 +829,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #elif FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);
 #endif
+      }   // !prime
 
-      // ================= 5. accepted iterate -> level k =================
+      // ================= 6. accepted iterate -> level k =================
       if (converged) {
-        if (t == 0) {
+        if (!prime && t == 0) {
           a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
           a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
           a.iters[(size_t)level * a.B + reach] = it;
         }
-        {
+        if (!prime) {
           // Level k+1 is rebuilt from registers, so the accepted state only has to reach HBM when
           // somebody can look at it: at the last level of this launch (fs_batch_get_state, next launch)
           // and, if a history is kept, at every level.  (A transposed, fully coalesced write-back
@@ -823,9 +848,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           R *const hQ_p = (DIAG && a.hist_h) ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
           if (last || hh_p) {
 #pragma unroll
-            for (int j = 0; j <= M; ++j) {
-              const int node = s0 + j;
-              if ((j < M || node == N - 1) && node < N) {
+            for (int j = 0; j < M; ++j) {
+              if (!RAGGED || s0 + j < N) {
                 if (last) { hk_p[j] = h[j]; Qk_p[j] = Q[j]; }
                 if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
               }
@@ -835,28 +859,48 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         FS_T(8);
         if (t == tD) {
 #pragma unroll
-          for (int j = kJD0; j <= M; ++j)
+          for (int j = RAGGED ? 0 : M - 1; j < M; ++j)
             if (j == jD) {
-              a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
-              a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
+              if (!prime) {
+                a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
+                a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
+              }
+              QoldD = Q[j];                                             // flow[k] of the next level's storage row
             }
-          Yprev = Ynew;
-          if (ds_storage) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
-        }
-        if (t == tD) {
-#pragma unroll
-          for (int j = kJD0; j <= M; ++j) if (j == jD) QoldD = Q[j];     // flow[k] of the next level's storage row
+          if (!prime) {
+            Yprev = Ynew;
+            if (ds_storage) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
+          }
         }
         FS_T(9);
-        if (kSaveTerms) level_constants_from_saved(h, Q);             // level constants of the next level
-        else write_level_constants(h, Q);
+        if (kSaveTerms) {                                             // level constants of the next level
+          if (prime) {                           // no fold has run yet: the node terms of the entry state go where a fold leaves them
+            NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+            save_terms(0, L);
+#pragma unroll
+            for (int c = 0; c < M; ++c) save_terms(c + 1, geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]));
+          }
+          level_constants_from_saved(h, Q);
+        } else {
+          write_level_constants(h, Q);
+        }
         FS_T(10);
       }
 
       FS_T(5);
+      if (prime) {                               // Newton start vector of the first level to solve
 #pragma unroll
-      for (int j = 0; j <= M; ++j) { h[j] += dh[j]; Q[j] += dQ[j]; }     // preissmann.py:146-147
+        for (int j = 0; j <= M; ++j) {
+          const int node = min(s0 + j, N - 1);
+          h[j] = a.hg[base + node];  Q[j] = a.Qg[base + node];
+        }
+        primed = true;
+      } else {
+#pragma unroll
+        for (int j = 0; j <= M; ++j) { h[j] += dh[j]; Q[j] += dQ[j]; }     // preissmann.py:146-147
+      }
     }
+    if (prime) continue;
     if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
     if (kBudget && a.iter_budget > 0) {
       if (t == 0) a.it_done[reach] = (converged || status != FS_OK) ? -1 : it;
@@ -865,10 +909,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   }
 
   // ---- Newton start vector of the next level + per-reach bookkeeping ----
+  if (primed) {                               // (a reach that came in failed keeps what it had)
 #pragma unroll
-  for (int j = 0; j <= M; ++j) {
-    const int node = s0 + j;
-    if ((j < M || node == N - 1) && node < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
+    for (int j = 0; j < M; ++j)
+      if (!RAGGED || s0 + j < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
   }
   if (t == 0) a.status[reach] = status;
   if (ds_storage && t == tD) a.Yprev[reach] = Yprev;

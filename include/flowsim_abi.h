@@ -122,7 +122,7 @@ enum {
 
 typedef struct fs_batch_desc {
   int32_t n_reaches;     /* B */
-  int32_t n_nodes;       /* N, 2..4097 */
+  int32_t n_nodes;       /* N, 2..4096 */
   int32_t dtype;         /* FS_F64 | FS_F32 */
   int32_t section_mode;  /* FS_SEC_* */
   int32_t device;        /* HIP device ordinal */

@@ -1,26 +1,37 @@
-"""Numpy model of the on-chip linear solve used by the HIP kernel (flow-sim_amd/csrc/fs_solve.hpp).
+"""Numpy model of the on-chip linear solve used by the HIP kernel (flow-sim_amd/csrc/fs_device.hpp, fs_kernel.hpp).
 
-Not the product and not the oracle: a lane-by-lane executable description of the device algorithm,
-kept in tests/ so its numerics (no pivoting, fixed elimination order) can be compared on the CPU
-with what the reference calls, scipy.sparse.linalg.spsolve (preissmann.py:146), on the Jacobians
-of the golden cases.
+Not the product and not the oracle: a lane-by-lane executable description of the device algorithm, kept in tests/ so
+that its numerics (no pivoting, fixed elimination order) can be compared on the CPU with what the reference calls,
+scipy.sparse.linalg.spsolve (preissmann.py:146), on the Jacobians of the golden cases.
 
 System (preissmann.py:874-897): unknowns d_i = (dh_i, dQ_i), i = 0..N-1;
-  U row      : u . d_0                      = ru
-  cell i     : C row  a_i . d_i + b_i . d_{i+1} = rc_i
-               M row  c_i . d_i + e_i . d_{i+1} = rm_i          i = 0..N-2
-  D row      : w . d_{N-1}                  = rd
+  U row      : u . d_0                          = ru
+  cell i     : C row  a_i . d_i + b_i . d_{i+1} = rc_i      a_i = (T_i/(2dt), -theta/dx), b_i = (T_{i+1}/(2dt), +theta/dx)
+               M row  c_i . d_i + e_i . d_{i+1} = rm_i      i = 0..N-2
+  D row      : w . d_{N-1}                      = rd
 
-Algorithm: `T` lanes, lane t owns cells [t*m, (t+1)*m) (padded with identity cells).
-  1. local fold: merge the lane's cells left to right into one condensed "segment"
-        C-like row  pc . d_s + sc . d_e = qc
-        M-like row  pm . d_s + sm . d_e = qm
-     pivoting each interior node on (M-like row of what is left of it, C row of the cell right of
-     it) - the block-Thomas order of the classical Preissmann double sweep - and keeping, per
-     eliminated node, what back-substitution needs.
-  2. tree: segments are merged pairwise with the same operation (log2 T levels), then the U and D
-     rows close the 4x4 system for (d_0, d_last); separators are recovered on the way down.
-  3. local back-substitution.
+Characteristic-like unknowns.  The continuity row has the same two numbers on both nodes (t_i = T_i/(2dt) on dh,
+-+cq = theta/dx on dQ), so with
+      p_i = t_i dh_i + cq dQ_i ,   m_i = t_i dh_i - cq dQ_i
+it reads  m_i + p_{i+1} = rc_i : every p but the first is an m and a number, no division.  What is left is ONE scalar
+tridiagonal system in (p_0, m_0, ..., m_{N-1}): row i is the momentum row of cell i,
+      alpha_i p_i + (beta_i - gamma_i) m_i + delta_i m_{i+1} = rm_i - gamma_i rc_i ,   p_i = rc_{i-1} - m_{i-1} (i > 0)
+      alpha, beta = c0/(2t_i) +- c1/(2cq) ,  gamma, delta = e0/(2t_{i+1}) +- e1/(2cq)
+followed by the D row (on p_{N-1}, m_{N-1}) and identity rows up to the lane grid; the U row closes the system on the
+left.  Frictionless and subcritical the rows are diagonally dominant, |beta - gamma| = 2(a + k) against |a - k + v| +
+|a - k - v| with a = theta dt (c^2 - v^2)/dx, k = dx/(4 theta dt): no pivoting, and none of the singular pivot blocks
+the 2x2 block order of the classical double sweep runs into on steep shallow reaches.
+
+Algorithm: `T` lanes, lane t owns the rows [t*m, (t+1)*m), m >= 2.
+  1. local fold, top to bottom: the running "down" row  d1 p_a + d2 m_j + d3 m_{j+1} = rd  (forward elimination with
+     the fill-in column of the lane's first unknown) and the running "up" row  u1 p_a + u2 m_a + u3 m_j = ru  (the
+     lane's first row with its last unknown substituted as the sweep moves on); per row three numbers (R1, R2, R3) for
+     the back-substitution  m_{j-1} = R3 - R1 p_a - R2 m_j.
+  2. tree: two adjacent segments (up, down, rc of the last row) merge by eliminating the left one's last unknown
+     from {left.down, right.up} - one 2x2 determinant; only m_{b-1} has to be substituted, m_b drops out; log2 T levels.
+     The root and the U row give (p_0, m_0, m_last).  On the way down every lane carries two numbers, the p of its
+     group's first row and the m of its last one; a level's record is (A1, A2, A3, rc_left).
+  3. local back-substitution, then dh = (p + m)/(2t), dQ = (p - m)/(2cq).
 """
 import numpy as np
 
@@ -35,91 +46,108 @@ def cells_from_reference_layout(data, R):
     return (np.array(data[0:2]), -R[0]), (a, b, rc, c, e, rm), (np.array(data[-2:]), -R[-1])
 
 
-def merge(A, B):
-    """Eliminate the node shared by segment A (left) and B (right).  Arrays over lanes.
-    A, B: dict(pc, sc, qc, pm, sm, qm) with pc.. of shape [..., 2]."""
-    det = A["sm"][..., 0] * B["pc"][..., 1] - A["sm"][..., 1] * B["pc"][..., 0]
-    r = 1.0 / det
-    w1 = np.stack([B["pc"][..., 1] * r, -B["pc"][..., 0] * r], -1)     # D^-1 column 1
-    w2 = np.stack([-A["sm"][..., 1] * r, A["sm"][..., 0] * r], -1)     # D^-1 column 2
-    al = np.sum(A["sc"] * w1, -1); be = np.sum(A["sc"] * w2, -1)
-    ga = np.sum(B["pm"] * w1, -1); ep = np.sum(B["pm"] * w2, -1)
-    out = dict(
-        pc=A["pc"] - al[..., None] * A["pm"], sc=-be[..., None] * B["sc"],
-        qc=A["qc"] - al * A["qm"] - be * B["qc"],
-        pm=-ga[..., None] * A["pm"], sm=B["sm"] - ep[..., None] * B["sc"],
-        qm=B["qm"] - ga * A["qm"] - ep * B["qc"])
-    elim = dict(w1=w1, w2=w2, pm=A["pm"], qm=A["qm"], sc=B["sc"], qc=B["qc"], det=det)
-    return out, elim
-
-
-def back(elim, dL, dR):
-    sig = elim["qm"] - np.sum(elim["pm"] * dL, -1)
-    tau = elim["qc"] - np.sum(elim["sc"] * dR, -1)
-    return elim["w1"] * sig[..., None] + elim["w2"] * tau[..., None]
-
-
-def solve(data, R, m, T=None):
-    """Returns delta[2N] with J delta = -R, computed with the device's elimination order."""
+def scalar_rows(data, R, dtype=np.float64):
+    """(alpha, D, delta, rho0, rc)[rows] of the tridiagonal system + what the closure and the conversion back need.
+    rho0 = rm - gamma rc; the fold subtracts alpha * rc of the row above (rows that do not start a lane)."""
     N = len(R) // 2
     (u, ru), (a, b, rc, c, e, rm), (w, rd) = cells_from_reference_layout(data, R)
-    nc = N - 1
+    cq = b[0, 1]
+    assert np.allclose(a[:, 1], -cq) and np.allclose(b[:, 1], cq)
+    t = np.empty(N)                       # t_i = T_i / (2 dt): the dh coefficient of the continuity rows at node i
+    t[:-1] = a[:, 0]; t[-1] = b[-1, 0]
+    assert np.allclose(b[:, 0], t[1:])
+    i2t, i2c = 0.5 / t, 0.5 / cq
+    X0, Y0 = c[:, 0] * i2t[:-1], c[:, 1] * i2c
+    X1, Y1 = e[:, 0] * i2t[1:], e[:, 1] * i2c
+    alpha, beta, gamma, delta = X0 + Y0, X0 - Y0, X1 + Y1, X1 - Y1
+    rows = dict(alpha=np.append(alpha, w[0] * i2t[-1] + w[1] * i2c),
+                D=np.append(beta - gamma, w[0] * i2t[-1] - w[1] * i2c),
+                delta=np.append(delta, 0.0),
+                rho0=np.append(rm - gamma * rc, rd),
+                rc=np.append(rc, 0.0))
+    rows = {k: v.astype(dtype) for k, v in rows.items()}
+    ub = (dtype(u[0] * i2t[0] + u[1] * i2c), dtype(u[0] * i2t[0] - u[1] * i2c), dtype(ru))      # aU p_0 + bU m_0 = ru
+    return rows, ub, i2t.astype(dtype), dtype(i2c)
+
+
+def merge(X, Y):
+    """Segments over lanes (arrays).  X left, Y right; returns the merged segment and the level's record."""
+    ru2 = Y["ru"] - Y["u1"] * X["rc"]                 # right rows on m_{b-1}: p_b = rc_left - m_{b-1}
+    rd2 = Y["rd"] - Y["d1"] * X["rc"]
+    det = X["d2"] * Y["u2"] + X["d3"] * Y["u1"]
+    r = 1.0 / det
+    g1, g2 = Y["u2"] * r, X["d3"] * r
+    A1, A2, A3 = g1 * X["d1"], g2 * Y["u3"], g1 * X["rd"] - g2 * ru2      # m_{b-1} = -A1 p_a + A2 m_{c-1} + A3
+    Z = dict(u1=X["u1"] - X["u3"] * A1, u2=X["u2"], u3=X["u3"] * A2, ru=X["ru"] - X["u3"] * A3,
+             d1=Y["d1"] * A1, d2=Y["d2"] - Y["d1"] * A2, d3=Y["d3"], rd=rd2 + Y["d1"] * A3, rc=Y["rc"])
+    return Z, dict(A1=A1, A2=A2, A3=A3, rc=X["rc"], det=det, scale=np.abs(X["d2"] * Y["u2"]) + np.abs(X["d3"] * Y["u1"]))
+
+
+def solve(data, R, m, T=None, dtype=np.float64):
+    """Returns (delta[2N] with J delta = -R computed with the device's elimination order, smallest pivot relative to
+    its terms)."""
+    N = len(R) // 2
+    assert m >= 2
+    rows, (aU, bU, rU), i2t, i2c = scalar_rows(data, R, dtype)
+    nr = N                                 # N - 1 cells + the D row
     if T is None:
         T = 1
-        while T * m < nc:
+        while T * m < nr:
             T *= 2
-    ncp = T * m
-    # identity padding: dh_i - dh_{i+1} = 0 ; dQ_i - dQ_{i+1} = 0
+    assert T * m >= nr
+    one, zero = dtype(1), dtype(0)
+
     def pad(x, fill):
-        out = np.empty((ncp,) + x.shape[1:]); out[:nc] = x; out[nc:] = fill; return out
-    a = pad(a, [1.0, 0.0]); b = pad(b, [-1.0, 0.0]); rc = pad(rc, 0.0)
-    c = pad(c, [0.0, 1.0]); e = pad(e, [0.0, -1.0]); rm = pad(rm, 0.0)
-    cell = lambda j: dict(pc=a[j::m][:T] if False else a.reshape(T, m, 2)[:, j], sc=b.reshape(T, m, 2)[:, j],
-                          qc=rc.reshape(T, m)[:, j], pm=c.reshape(T, m, 2)[:, j], sm=e.reshape(T, m, 2)[:, j],
-                          qm=rm.reshape(T, m)[:, j])
+        out = np.full(T * m, fill, dtype=dtype); out[:nr] = x; return out.reshape(T, m)
+    al, D, de, rho0, rc = (pad(rows["alpha"], zero), pad(rows["D"], one), pad(rows["delta"], zero),
+                           pad(rows["rho0"], zero), pad(rows["rc"], zero))
     # 1. local fold
-    seg = cell(0)
-    local = []
-    mindet = np.inf
+    d1, d2, d3, rd = al[:, 0].copy(), D[:, 0].copy(), de[:, 0].copy(), rho0[:, 0].copy()
+    u1, u2, u3, ru = np.zeros(T, dtype), np.ones(T, dtype), -np.ones(T, dtype), np.zeros(T, dtype)
+    rec = []
+    worst = np.inf
     for j in range(1, m):
-        seg, el = merge(seg, cell(j))
-        local.append(el)
-        mindet = min(mindet, np.min(np.abs(el["det"])))
-    # 2. tree up-sweep over lanes
+        r = one / d2
+        R1, R2, R3 = d1 * r, d3 * r, rd * r                   # m_{j-1} = R3 - R1 p_a - R2 m_j
+        rec.append((R1, R2, R3))
+        rho = rho0[:, j] - al[:, j] * rc[:, j - 1]
+        newd2 = D[:, j] + al[:, j] * R2
+        worst = min(worst, np.min(np.abs(newd2) / (np.abs(D[:, j]) + np.abs(al[:, j] * R2))))
+        d1, d2, d3, rd = al[:, j] * R1, newd2, de[:, j], rho + al[:, j] * R3
+        u1, u3, ru = u1 - u3 * R1, -u3 * R2, ru - u3 * R3
+    seg = dict(u1=u1, u2=u2, u3=u3, ru=ru, d1=d1, d2=d2, d3=d3, rd=rd, rc=rc[:, m - 1])
+    # 2. tree
     levels = []
-    segs = seg
-    cur_T = T
-    while cur_T > 1:
-        A = {k: v[0::2] for k, v in segs.items()}
-        B = {k: v[1::2] for k, v in segs.items()}
-        segs, el = merge(A, B)
+    while len(seg["u1"]) > 1:
+        X = {k: v[0::2] for k, v in seg.items()}
+        Y = {k: v[1::2] for k, v in seg.items()}
+        seg, el = merge(X, Y)
         levels.append(el)
-        mindet = min(mindet, np.min(np.abs(el["det"])))
-        cur_T //= 2
-    S = {k: v[0] for k, v in segs.items()}
-    # close with the boundary rows: block row 0 = {U, C-like}, last = {M-like, D}
-    D0 = np.array([u, S["pc"]])
-    D0i = np.linalg.inv(D0)
-    # d_0 = D0i @ ([ru, qc] - [0, sc . d_last])
-    g0 = D0i @ np.array([ru, S["qc"]])
-    x0 = D0i[:, 1]                                   # d_0 = g0 - x0 * (sc . d_last)
-    # M-like: pm . d_0 + sm . d_last = qm
-    rowM = S["sm"] - (S["pm"] @ x0) * S["sc"]
-    rhsM = S["qm"] - S["pm"] @ g0
-    dl = np.linalg.solve(np.array([rowM, w]), np.array([rhsM, rd]))
-    d0 = g0 - x0 * (S["sc"] @ dl)
-    # down-sweep: separators sep[t] = delta at the left end of lane t's chunk, sep[T] = last
-    left = np.array([d0]); right = np.array([dl])
+        worst = min(worst, np.min(np.abs(el["det"]) / el["scale"]))
+    S = {k: v[0] for k, v in seg.items()}
+    # root: up  u1 p_0 + u2 m_0 + u3 m_last = ru ; down  d1 p_0 + d2 m_last = rd (nothing right of the last row) ; U row
+    r = one / S["d2"]
+    e1, e3 = S["u1"] - S["u3"] * S["d1"] * r, S["ru"] - S["u3"] * S["rd"] * r        # e1 p_0 + u2 m_0 = e3
+    det = aU * S["u2"] - bU * e1
+    worst = min(worst, abs(det) / (abs(aU * S["u2"]) + abs(bU * e1)))
+    p0 = (rU * S["u2"] - bU * e3) / det
+    mlast = (S["rd"] - S["d1"] * p0) * r
+    pL, mR = np.array([p0], dtype), np.array([mlast], dtype)
     for el in reversed(levels):
-        mid = back(el, left, right)
-        nl = np.empty((2 * len(left), 2)); nr = np.empty_like(nl)
-        nl[0::2] = left; nl[1::2] = mid
-        nr[0::2] = mid; nr[1::2] = right
-        left, right = nl, nr
-    # 3. local back-substitution (right to left)
-    d = np.empty((T, m + 1, 2))
-    d[:, 0] = left; d[:, m] = right
+        sep = -el["A1"] * pL + el["A2"] * mR + el["A3"]              # m of the left half's last row
+        npL = np.empty(2 * len(pL), dtype); nmR = np.empty_like(npL)
+        npL[0::2] = pL; npL[1::2] = el["rc"] - sep
+        nmR[0::2] = sep; nmR[1::2] = mR
+        pL, mR = npL, nmR
+    # 3. local back-substitution
+    mm = np.empty((T, m), dtype); pp = np.empty((T, m), dtype)
+    mm[:, m - 1] = mR; pp[:, 0] = pL
     for j in range(m - 1, 0, -1):
-        d[:, j] = back(local[j - 1], left, d[:, j + 1])
-    full = np.concatenate([d[:, :m].reshape(T * m, 2), d[-1:, m]], 0)
-    return full[:N].reshape(-1), mindet
+        R1, R2, R3 = rec[j - 1]
+        mm[:, j - 1] = R3 - R1 * pL - R2 * mm[:, j]
+        pp[:, j] = rc[:, j - 1] - mm[:, j - 1]
+    p, mv = pp.reshape(-1)[:N], mm.reshape(-1)[:N]
+    out = np.empty(2 * N, dtype)
+    out[0::2] = (p + mv) * i2t
+    out[1::2] = (p - mv) * i2c
+    return out, worst

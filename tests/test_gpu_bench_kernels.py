@@ -146,8 +146,8 @@ def test_dispatch_prefers_the_most_specific_instantiation():
     from fixture_batch import batch_from_problems
     want = {                                   # N -> (M, W, full, class with / without history)
         4096: (16, 4, 1, 2 + A.BC_NORMAL_DEPTH), 4000: (16, 4, 0, 2 + A.BC_NORMAL_DEPTH), 2048: (16, 2, 1, 2 + A.BC_NORMAL_DEPTH),
-        1024: (16, 1, 1, 2 + A.BC_NORMAL_DEPTH), 513: (8, 1, 1, 2 + A.BC_NORMAL_DEPTH), 300: (8, 1, 0, 2 + A.BC_NORMAL_DEPTH),
-        200: (4, 1, 0, 1), 100: (2, 1, 0, 1), 40: (1, 1, 0, 1), 2000: (16, 2, 0, 1),
+        1024: (16, 1, 1, 2 + A.BC_NORMAL_DEPTH), 512: (8, 1, 1, 2 + A.BC_NORMAL_DEPTH), 300: (8, 1, 0, 2 + A.BC_NORMAL_DEPTH),
+        513: (16, 1, 0, 1), 200: (4, 1, 0, 1), 100: (2, 1, 0, 1), 40: (2, 1, 0, 1), 2000: (16, 2, 0, 1),
     }
     for N, (M, W, full, bck) in want.items():
         p = rect_problem(N, seed=3, n_steps=2)

@@ -43,10 +43,10 @@ def _id(e):
 
 
 def _nodes(e):
-    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]
+    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]      # rows of the scalar system: N - 1 cells + the boundary row
     if e["full"]:
-        return cap + 1 - (e["index"] % 2)          # N - 1 in {cap - 1, cap}: both full-chunk layouts over the table
-    return max(2, cap - 2 - e["index"] % 5) + 1      # ragged: 2..6 cells short of the capacity
+        return cap
+    return max(2, cap - 1 - e["index"] % 5)          # ragged: 1..5 rows short of the capacity
 
 
 # boundary pairs for the general classes, rotated over the entries: (upstream, downstream)
@@ -149,7 +149,8 @@ def case_for(e):
             assert bck - 2 == A.BC_RATING_BLEND and cap >= 120
             return fixture_problem("gerd", 6), "table", None
         # class 0: compound sections going over bank where the capacity allows, else the table of a plain trapezoid
-        if cap >= 120 and e["index"] % 2:
+        # (fp32 cannot take the central difference of the Roseires gate curve: 1 mm on a stage of 487 m is 30 ulp)
+        if cap >= 120 and e["index"] % 2 and e["dtype"] == A.F64:
             return fixture_problem("gerd", 5), "table", None
         return fixture_problem("bc_compound_normal" if e["index"] % 3 else "bc_trap_poly", 8), "table", None
     if sec == A.SEC_IRREGULAR:
@@ -180,7 +181,7 @@ def test_instantiation_against_the_oracle(e, monkeypatch):
     if f32:
         p.tol = 1e-3 if p.N <= 600 else 2e-2      # fp32 cannot resolve ||R|| below ~6e-8 |Q| sqrt(2N) (bench.py uses the same)
     cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]
-    assert p.N - 1 <= cap, "recipe does not fit the entry"
+    assert p.N <= cap, "recipe does not fit the entry"
     ref = oracle_run(p)
     assert ref["status"] == 0
     monkeypatch.setenv("FS_KERNEL_INDEX", str(e["index"]))
@@ -220,7 +221,7 @@ def test_the_table_is_what_this_file_expects():
                 ("ds", "fixed_depth", None, True), ("ds", "normal_depth", None, False), ("ds", "rating_curve", "power", False),
                 ("ds", "rating_curve", "polynomial", False), ("ds", "rating_curve", "blend", False)):
         assert key in seen, key
-    os.environ["FS_KERNEL_INDEX"] = "0"            # entry 0 is an fp64 rectangular (1,1) kernel: 64 cells at most
+    os.environ["FS_KERNEL_INDEX"] = "0"            # entry 0 is an fp64 rectangular (2,1) kernel: 128 nodes at most
     try:
         from synth import rect_problem
         from fixture_batch import batch_from_problems

@@ -1,4 +1,4 @@
-"""The device's unpivoted chunk-fold + tree elimination (modelled lane by lane in
+"""The device's unpivoted scalar-tridiagonal chunk-fold + tree elimination (modelled lane by lane in
 tests/partition_model.py) against scipy.sparse.linalg.spsolve, the routine the reference calls
 (preissmann.py:146), on Jacobians assembled by the oracle from the golden cases."""
 import os
@@ -14,7 +14,7 @@ import partition_model as PM
 
 
 @pytest.mark.parametrize("name", ["akbari", "example", "gerd", "bc_compound_normal", "synthetic_rect_512"])
-@pytest.mark.parametrize("m", [1, 2, 8, 16])
+@pytest.mark.parametrize("m", [2, 4, 8, 16])
 def test_partition_solve_matches_superlu(name, m):
     fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
     p = O.problem_from_fixture(fx, meta, 0 if meta.get("B") else None)
@@ -26,8 +26,8 @@ def test_partition_solve_matches_superlu(name, m):
         R, data, _ = O.assemble(p, h, Q, p.h0, p.Q0, 1, store)
         J = sp.coo_matrix((data, (rows, cols)), shape=(2 * N, 2 * N)).tocsr()
         d = spla.spsolve(J, -R)
-        d2, mindet = PM.solve(data, R, m)
+        d2, worst = PM.solve(data, R, m)
         for sl in (slice(0, None, 2), slice(1, None, 2)):
             assert np.max(np.abs(d2[sl] - d[sl])) <= 1e-10 * max(np.max(np.abs(d[sl])), 1e-300)
-        assert mindet > 0
+        assert worst > 1e-3          # no pivot lost more than three digits to cancellation
         h, Q = h + d[0::2], Q + d[1::2]
