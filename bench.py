@@ -9,9 +9,11 @@ Workload (BASELINE.json configs[2], SURVEY.md 8d "C3"): per GPU 65 536 synthetic
 reaches x 4 096 nodes, fp64, constant Manning n per reach, upstream flow hydrograph (akbari
 shape), downstream normal depth, steady-state initial condition, theta 0.6, dt 600 s, dx 250 m,
 tolerance 1e-6.  One "step" = one time level (full Newton loop) of every reach in the batch.
-Weak scaling: every rank owns its own block of 65 536 reaches (global reach index seeds the
-draws); the only collective is one RCCL all_gather of the boundary hydrographs, inside the timed
-region.  Inputs are resident in HBM before the timed region.
+Weak scaling (default): every rank owns its own block of --reaches reaches (global reach index seeds
+the draws).  Strong scaling (--total-reaches T): T reaches in all, split into contiguous blocks over
+the ranks (flowsim_amd.shard.split_reaches; north_star quotes 65 536 reaches in total at 8 GPUs).  The
+only collective is one RCCL all_gather of the boundary hydrographs, inside the timed region.  Inputs
+are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     - algorithmic HBM bytes of the step kernel / its HIP-event time, vs 8 TB/s
@@ -37,7 +39,28 @@ FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64, the unit this kernel actually runs
 
 from flowsim_amd.synthetic import (c3_reach_parameters, c5_reach_parameters, inflow_table,  # noqa: E402
                                    normal_depth_rect, normal_depth_trap)
-from flowsim_amd.shard import gather_hydrographs, reach_block  # noqa: E402
+from flowsim_amd.shard import gather_hydrographs, gather_hydrographs_split, reach_block, split_reaches  # noqa: E402
+
+
+def library_sha256():
+    import hashlib
+    from flowsim_amd import _abi
+    return hashlib.sha256(open(os.path.normpath(os.environ.get("FS_LIB", _abi.LIB_PATH)), "rb").read()).hexdigest()
+
+
+def load_profile(workload, dtype, N, entry):
+    """HBM traffic / flop counts of this workload's step kernel from the committed rocprofv3 PMC passes
+    (profiles/round2/<workload>_<dtype>.json, tools/refresh_profiles.py) - only if they were taken on the very library
+    that is loaded now and on the same instantiation; a stale file gives None (traffic: null) rather than a wrong number."""
+    path = os.path.join(ROOT, "profiles", "round2", f"{workload}_{dtype}.json")
+    if not os.path.exists(path):
+        return None
+    p = json.load(open(path))
+    same_kernel = all(p["kernel"].get(k) == entry[k] for k in ("cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag"))
+    if p.get("library_sha256") != library_sha256() or p.get("nodes") != N or not same_kernel:
+        return None
+    p["file"] = os.path.relpath(path, ROOT)
+    return p
 
 
 def cpu_baseline(N, dt, dx, theta, tol, budget_s=9.0, compiled=False):
@@ -129,7 +152,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU")
+    ap.add_argument("--reaches", type=int, default=65536, help="reaches per GPU (weak scaling)")
+    ap.add_argument("--total-reaches", type=int, default=None,
+                    help="strong scaling: this many reaches in total, split over the ranks in contiguous blocks")
     ap.add_argument("--nodes", type=int, default=4096)
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c4", "irr"],
@@ -137,7 +162,7 @@ def main():
                          "rating curve (use with --dtype f32 --nodes 512 --reaches 131072); c4: cases/gerd_roseires "
                          "geometry with a Manning-n Monte-Carlo ensemble (use with --reaches 32768; nodes fixed at 121); irr: "
                          "polyline (IrregularSection) channel with a levee, Manning-n ensemble (use with --reaches 8192; "
-                         "129 nodes)")
+                         "128 nodes)")
     ap.add_argument("--spatial-step", type=float, default=None,
                     help="c4 only: override the case's spatial step (m); the node count follows (default 1000 m: 121 nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -168,9 +193,16 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    B, N, K, Wm = args.reaches, args.nodes, args.steps, args.warmup
+    N, K, Wm = args.nodes, args.steps, args.warmup
     levels = K + Wm + 1
-    first, _ = reach_block(rank, world, B)
+    strong = args.total_reaches is not None
+    if strong:
+        first, B = split_reaches(args.total_reaches, rank, world)
+        if B < 1:
+            raise SystemExit("--total-reaches must give every rank at least one reach")
+    else:
+        B = args.reaches
+        first, _ = reach_block(rank, world, B)
     if args.workload == "c3":
         # fp32 cannot resolve ||R|| below ~6e-8 |Q| sqrt(2N) (1e-2 for the largest of these reaches): its tolerance follows
         theta, dt, dx, tol = 0.6, 600.0, 250.0, (1e-6 if args.dtype == "f64" else 2e-2)
@@ -210,7 +242,7 @@ def main():
         # composite roughness over three strips, one channel shared by a Manning-n ensemble
         from flowsim_amd.hydromodel import Boundary, Channel, Hydrograph, IrregularSection, PreissmannSolver
         from flowsim_amd.hydromodel.preissmann import boundary_to_spec
-        Lc, S0c = 64000.0, 3e-4
+        Lc, S0c = 63500.0, 3e-4                # 127 cells of 500 m: 128 nodes, the capacity of the two-rows-per-lane kernel
         xa = np.array([0, 10, 14, 30, 34, 60, 66, 80.0]); za = np.array([8, 3.0, 0.4, 0.0, 0.6, 2.5, 2.8, 8.0])
         xb = np.array([0, 12, 18, 33, 41, 58, 70, 90.0]); zb = np.array([7.5, 2.6, 0.3, 0.0, 0.5, 2.0, 2.6, 7.5])
         secs = []
@@ -279,16 +311,22 @@ def main():
     if world > 1:
         # untimed rehearsal of the one collective of the path (same shape): communicator channels and
         # RCCL's staging buffers are set up on first use
-        warm = hyd_dev[1:1 + K]
-        gather_hydrographs(warm if args.backend == "nccl" else warm.cpu(), world)
+        warm = hyd_dev[1:1 + K] if args.backend == "nccl" else hyd_dev[1:1 + K].cpu()
+        gather_hydrographs_split(warm, args.total_reaches, world) if strong else gather_hydrographs(warm, world)
     barrier()
     t0 = time.perf_counter()
     batch.step(K, sync=False)
     batch.sync()
-    # the only exchange of the path: boundary hydrographs of the timed levels, [K, 4, world*B] on every rank
+    # the only exchange of the path: boundary hydrographs of the timed levels, [K, 4, all reaches] on every rank
     timed_rows = hyd_dev[Wm + 1:Wm + 1 + K]
-    gathered = gather_hydrographs(timed_rows if args.backend == "nccl" or world == 1 else timed_rows.cpu(), world)
-    assert gathered.shape == (K, 4, world * B)
+    if args.backend != "nccl" and world > 1:
+        timed_rows = timed_rows.cpu()
+    if strong:
+        gathered = gather_hydrographs_split(timed_rows, args.total_reaches, world)
+        assert gathered.shape == (K, 4, args.total_reaches)
+    else:
+        gathered = gather_hydrographs(timed_rows, world)
+        assert gathered.shape == (K, 4, world * B)
     barrier()
     el = time.perf_counter() - t0
     kern_ms = batch.last_step_ms()
@@ -298,53 +336,52 @@ def main():
     ok = bool(np.all(st == 0))
     el_t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
     kms_t = torch.tensor([kern_ms], dtype=torch.float64, device=f"cuda:{local}")
-    it_t = torch.tensor([float(its.sum()), float(ok)], dtype=torch.float64, device=f"cuda:{local}")
+    it_t = torch.tensor([float(its.sum()), float(ok), float(B)], dtype=torch.float64, device=f"cuda:{local}")
     if world > 1:
         if args.backend != "nccl":
             el_t, kms_t, it_t = el_t.cpu(), kms_t.cpu(), it_t.cpu()
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(kms_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
-    el = float(el_t.item()); kern_ms = float(kms_t.item())
+    el = float(el_t.item()); kern_ms_max = float(kms_t.item())
     info = batch.kernel_info()
+    kidx = batch.kernel_index()
 
     if rank == 0:
-        total = float(B) * K * world
+        total = float(it_t[2].item()) * K               # reaches of all ranks x timed levels
         real = 8 if args.dtype == "f64" else 4
-        traffic = None      # HBM bytes per launch from the committed rocprofv3 PMC passes (same workload shape)
-        tj = os.path.join(ROOT, "profiles", "round1", "hbm_traffic.json")
-        if os.path.exists(tj) and N == 4096 and args.dtype == "f64":
-            traffic = json.load(open(tj))["hbm_bytes_per_reach_timestep"] * float(B) * K
+        # roofline of the step kernel on THIS rank's GPU: algorithmic bytes of its launch / its own HIP-event time
         alg_bytes_launch = float(B) * K * (4 * N * real + 8 + 32)      # state in+out, BC target, hydrograph row
         ach = alg_bytes_launch / (kern_ms * 1e-3) / 1e9
         mean_its = float(it_t[0].item()) / total
         status_counts = {int(k): int(v) for k, v in zip(*np.unique(st, return_counts=True))}
+        entry = A.kernel_table()[kidx]
+        prof = load_profile(args.workload, args.dtype, N, entry)
         out = {
             "metric": "reach-timesteps/sec (batched Preissmann Newton step)",
             "value": total / el, "unit": "reach-timesteps/s", "n_gpus": world, "steps": K, "warmup": Wm,
-            "ms_per_step": el * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": el * 1e3 / K, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": desc,
-                       "reaches_per_gpu": B, "nodes": N, "parallelism": f"reach-sharded x{world}",
+                       "reaches_per_gpu": B, "total_reaches": int(it_t[2].item()), "nodes": N, "parallelism": f"reach-sharded x{world}",
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
                        "status_counts_rank0": status_counts,
-                       "kernel": info},
+                       "kernel": dict(info, table_index=kidx, boundary_class=entry["boundary_class"], full=entry["full"], diag=entry["diag"]),
+                       "kernel_ms_max_over_ranks": kern_ms_max},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/round1/hbm_traffic.json (rocprofv3 FETCH_SIZE + WRITE_SIZE, per reach-timestep x units of this launch)",
+                         "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None if prof is None else prof["hbm_bytes_per_reach_timestep"] * float(B) * K,
+                         "traffic_source": None if prof is None else prof["file"] + ": " + prof["traffic_note"],
                          "kernel": "preissmann_step_kernel", "kernel_ms": kern_ms, "launches": 1,
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
-                         "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 5"},
+                         "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 4"},
         }
-        fj = os.path.join(ROOT, "profiles", "round1", "fp64_flops.json")
-        if os.path.exists(fj) and N == 4096 and args.dtype == "f64" and args.workload == "c3":
-            # informational second roofline: the kernel is bound by fp64 vector issue, not by HBM
-            fpi = json.load(open(fj))["fp64_flops_per_reach_iteration"]
-            tf = fpi * float(it_t[0].item()) / world / (kern_ms * 1e-3) / 1e12
-            out["roofline_compute"] = {"bound": "valu_f64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                       "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
-                                       "source": "profiles/round1/fp64_flops.json (rocprofv3 SQ_INSTS_VALU_*_F64 per Newton iteration "
-                                                 "x the iterations of this launch)"}
+        if prof is not None and prof.get("flops_per_reach_iteration"):
+            # informational second roofline: the kernel is bound by vector issue, not by HBM
+            tf = prof["flops_per_reach_iteration"] * float(its.sum()) / (kern_ms * 1e-3) / 1e12
+            peak = FP64_VECTOR_PEAK_TFLOPS * (1 if args.dtype == "f64" else 2)
+            out["roofline_compute"] = {"bound": "valu_" + args.dtype, "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                                       "source": prof["file"] + " (rocprofv3 SQ_INSTS_VALU_* per Newton iteration x the iterations of this launch)"}
         if not args.no_cpu_baseline and args.workload == "c3" and world == 1:      # reported at N=1 only
             host_cores = set(os.sched_getaffinity(0))
             out["cpu_baseline"] = cpu_baseline(N, dt, dx, theta, tol)

@@ -29,3 +29,22 @@ def gather_hydrographs(local: torch.Tensor, world: int) -> torch.Tensor:
     out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local)
     return out.permute(1, 2, 0, 3).reshape(local.shape[0], local.shape[1], world * local.shape[2])
+
+
+def gather_hydrographs_split(local: torch.Tensor, total: int, world: int) -> torch.Tensor:
+    """The same gather for the strong-scaling layout (split_reaches): the blocks differ by at most one reach, the
+    shorter ones travel padded by a column (all_gather wants equal shapes) that is dropped again on arrival.
+    local [levels, 4, count(rank)] -> [levels, 4, total] in global reach order (all ranks)."""
+    if world == 1:
+        return local
+    counts = [split_reaches(total, r, world)[1] for r in range(world)]
+    widest = max(counts)
+    if local.shape[2] != widest:
+        padded = torch.zeros(local.shape[:2] + (widest,), dtype=local.dtype, device=local.device)
+        padded[:, :, :local.shape[2]] = local
+        local = padded
+    out = gather_hydrographs(local, world)
+    if min(counts) == widest:
+        return out
+    keep = torch.cat([torch.arange(r * widest, r * widest + c, device=out.device) for r, c in enumerate(counts)])
+    return out.index_select(2, keep)

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from flowsim_amd.shard import gather_hydrographs, reach_block, split_reaches
+from flowsim_amd.shard import gather_hydrographs, gather_hydrographs_split, reach_block, split_reaches
 from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
 
 N, STEPS, PER_RANK, DT, DX = 12, 3, 3, 600.0, 250.0
@@ -39,13 +39,21 @@ def hydrographs_of_block(first, count):
     return out
 
 
-def _worker(rank, world, port, q):
+TOTAL_STRONG = 7      # strong scaling: 7 reaches over 2 ranks = blocks of 4 and 3
+
+
+def _worker(rank, world, port, q, strong=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, count = reach_block(rank, world, PER_RANK)
-    local = torch.from_numpy(hydrographs_of_block(first, count))
-    allh = gather_hydrographs(local, world)
+    if strong:      # bench.py --total-reaches: contiguous blocks of unequal size, the shorter one travels padded
+        first, count = split_reaches(TOTAL_STRONG, rank, world)
+        local = torch.from_numpy(hydrographs_of_block(first, count))
+        allh = gather_hydrographs_split(local, TOTAL_STRONG, world)
+    else:
+        first, count = reach_block(rank, world, PER_RANK)
+        local = torch.from_numpy(hydrographs_of_block(first, count))
+        allh = gather_hydrographs(local, world)
     dist.barrier()
     if rank == 0:
         q.put(allh.numpy())
@@ -68,6 +76,25 @@ def test_two_rank_gather_equals_single_process():
     want = hydrographs_of_block(0, 2 * PER_RANK)
     assert got.shape == want.shape == (STEPS + 1, 4, 2 * PER_RANK)
     assert np.array_equal(got, want)            # shard-invariant, bit for bit
+
+
+def test_two_rank_strong_scaling_gather_equals_single_process():
+    """the --total-reaches path of bench.py: split_reaches + gather_hydrographs_split at world size 2"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, True)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = hydrographs_of_block(0, TOTAL_STRONG)
+    assert got.shape == want.shape == (STEPS + 1, 4, TOTAL_STRONG)
+    assert np.array_equal(got, want)
 
 
 def test_parameter_stream_is_shard_invariant():

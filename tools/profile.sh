@@ -1,16 +1,27 @@
 #!/bin/bash
-# rocprofv3 runs for profiles/: kernel trace + stats, then HBM traffic counters in separate passes
-# (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE do not fit one pass; never combine --pmc with sys traces)
+# rocprofv3 passes for profiles/round2:  tools/profile.sh TAG <bench.py arguments ...>
+#   kernel trace + stats, then the HBM traffic counters in separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
+#   do not fit one pass; counters are never combined with system traces), the issue counters and the flop counters.
+# Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round2/.
 set -e
+TAG=$1; shift
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof
-mkdir -p $OUT
+OUT=$ROOT/gpurun_out/prof/$TAG
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--reaches 65536 --steps 8 --warmup 2 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || true
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || true
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err || true
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err || true
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 --kernel-trace --output-format csv -d $OUT/pmc_flops -- python3 $ROOT/bench.py $ARGS > $OUT/bench_flops.json 2> $OUT/flops.err || true
-find $OUT -name "*.csv" | head -50
+ARGS="$* --no-cpu-baseline"
+echo "$ARGS" > $OUT/args.txt
+sha256sum $ROOT/flow-sim_amd/csrc/libflowsim_hip.so | cut -d' ' -f1 > $OUT/library_sha256.txt
+pass() { name=$1; shift; rocprofv3 "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$name.json 2> $OUT/$name.err || true; }
+pass trace --stats
+pass pmc_fetch --pmc FETCH_SIZE
+pass pmc_write --pmc WRITE_SIZE
+pass pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU
+pass pmc_wait --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM
+if [ "${FS_F32:-0}" = "1" ]; then
+  pass pmc_flops --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32
+else
+  pass pmc_flops --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64
+fi
+find $OUT -name "*.csv" | wc -l
 du -sh $OUT

@@ -1,38 +1,81 @@
-"""Copies the newest rocprofv3 summaries from gpurun_out/prof (tools/profile.sh) into profiles/round1."""
-import csv, glob, json, os, shutil
-P, D = 'gpurun_out/prof', 'profiles/round1'
-newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1]
-shutil.copy(newest(f'{P}/trace/runc/*_kernel_stats.csv'), f'{D}/kernel_stats.csv')
-q = lambda r: ','.join('"%s"' % c for c in r)
-rows = list(csv.reader(open(newest(f'{P}/trace/runc/*_kernel_trace.csv'))))
-open(f'{D}/kernel_trace_preissmann.csv', 'w').write('\n'.join(q(r) for r in rows if r and (r[0] == 'Kind' or 'preissmann' in ','.join(r))) + '\n')
-vals = {}
-for name in ('pmc_fetch', 'pmc_write', 'pmc_sq', 'pmc_flops'):
-    rows = list(csv.reader(open(newest(f'{P}/{name}/runc/*_counter_collection.csv'))))
-    keep = [r for r in rows if r and (r[0] == 'Correlation_Id' or 'preissmann' in ','.join(r))]
-    open(f'{D}/{name}_preissmann.csv', 'w').write('\n'.join(q(r) for r in keep) + '\n')
-    h = keep[0]; ci, cv, di = h.index('Counter_Name'), h.index('Counter_Value'), h.index('Dispatch_Id')
-    last = max(int(r[di]) for r in keep[1:])
-    vals.update({r[ci]: float(r[cv]) for r in keep[1:] if int(r[di]) == last})
-B, K = 65536, 8
-fetch, write = vals['FETCH_SIZE'] * 1024, vals['WRITE_SIZE'] * 1024
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh, round 1 (final kernel)",
-           "workload": "65536 reaches x 4096 nodes, 8 steps in one launch", "fetch_bytes_per_launch": fetch,
-           "write_bytes_per_launch": write,
-           "fetch_note": "raw counter x 1024; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, this kernel reads 8 B/lane (uncalibrated)",
-           "hbm_bytes_per_reach_timestep": (fetch + write) / (B * K)}, open(f'{D}/hbm_traffic.json', 'w'), indent=1)
-print(open(f'{D}/kernel_stats.csv').read().split('\n')[1][:200])
-print('fetch GB', fetch / 1e9, 'write GB', write / 1e9, 'per reach-timestep', (fetch + write) / (B * K))
-w = vals['SQ_WAVES']
-print({k: f'{v / w:.4g}' for k, v in vals.items() if k.startswith('SQ_INSTS')}, 'valu active', vals['SQ_ACTIVE_INST_VALU'] / vals['SQ_WAVE_CYCLES'])
+"""Condenses the rocprofv3 passes of tools/profile.sh TAG (gpurun_out/prof/TAG) into profiles/round2/:
 
-# fp64 work per Newton iteration of one reach (wave-instruction counts x 64 lanes; an FMA is two flops)
-bj = json.loads(open(f'{P}/bench_flops.json').read().strip().split('\n')[-1])
-its = bj['config']['mean_newton_iterations_per_step']
-flops = 64 * (2 * vals['SQ_INSTS_VALU_FMA_F64'] + vals['SQ_INSTS_VALU_MUL_F64'] + vals['SQ_INSTS_VALU_ADD_F64'] + vals['SQ_INSTS_VALU_TRANS_F64'])
-json.dump({"source": "rocprofv3 --pmc SQ_INSTS_VALU_{FMA,MUL,ADD,TRANS}_F64 (tools/profile.sh), last launch of the run",
-           "workload": "65536 reaches x 4096 nodes, 8 steps in one launch", "mean_newton_iterations_per_step": its,
-           "fp64_flops_per_launch": flops, "fp64_flops_per_reach_iteration": flops / (B * K * its),
-           "valu_instructions_per_wave_iteration": vals['SQ_INSTS_VALU'] / vals['SQ_WAVES'] / (K * its)},
-          open(f'{D}/fp64_flops.json', 'w'), indent=1)
-print('fp64 flops per reach-iteration', flops / (B * K * its))
+    TAG_kernel_stats.csv        per-kernel totals / averages of the --kernel-trace --stats pass
+    TAG_counters.csv            every counter of the step kernel's LAST launch (the timed one), one row per counter
+    TAG.json                    what bench.py reads: HBM bytes per reach-timestep (FETCH_SIZE x 2 + WRITE_SIZE, see below),
+                                flops per reach and Newton iteration, issue statistics, the instantiation that ran and the
+                                sha256 of the library it ran from (bench.py ignores the file when either differs)
+
+FETCH_SIZE correction (MI355X_MICROARCH.md, HBM section): on gfx950 the counter tallies 128-byte read requests at 64 bytes,
+i.e. reports half of the bytes of a coalesced streaming read - "double it before comparing with a byte count; other access
+widths: calibrate on a known byte count".  This kernel's mandatory reads are known exactly (hk, Qk, hg, Qg once per launch:
+4 B N sizeof(real)); the file records them next to the doubled counter so that the calibration is visible.
+usage: python tools/refresh_profiles.py TAG [--kernel preissmann|derive]"""
+import argparse, csv, glob, json, os, shutil, sys
+
+ap = argparse.ArgumentParser()
+ap.add_argument("tag")
+ap.add_argument("--kernel", default="preissmann")
+ap.add_argument("--round", default="round2")
+a = ap.parse_args()
+P, D = f"gpurun_out/prof/{a.tag}", f"profiles/{a.round}"
+os.makedirs(D, exist_ok=True)
+newest = lambda pat: sorted(glob.glob(pat, recursive=True), key=os.path.getmtime)[-1]
+shutil.copy(newest(f"{P}/trace/**/*_kernel_stats.csv"), f"{D}/{a.tag}_kernel_stats.csv")
+bench = json.loads(open(f"{P}/bench_trace.json").read().strip().split("\n")[-1])
+vals = {}
+for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_wait", "pmc_flops"):
+    try:
+        rows = list(csv.reader(open(newest(f"{P}/{name}/**/*_counter_collection.csv"))))
+    except IndexError:
+        print("missing pass", name, file=sys.stderr)
+        continue
+    h = rows[0]
+    ci, cv, di, kn = h.index("Counter_Name"), h.index("Counter_Value"), h.index("Dispatch_Id"), h.index("Kernel_Name")
+    keep = [r for r in rows[1:] if a.kernel in r[kn]]
+    last = max(int(r[di]) for r in keep)
+    vals.update({r[ci]: float(r[cv]) for r in keep if int(r[di]) == last})
+    kernel_name = keep[-1][kn]
+with open(f"{D}/{a.tag}_counters.csv", "w") as f:
+    f.write('"Kernel_Name","Counter_Name","Counter_Value (last launch)"\n')
+    for k, v in sorted(vals.items()):
+        f.write(f'"{kernel_name[:120]}","{k}",{v:.17g}\n')
+stats = list(csv.DictReader(open(f"{D}/{a.tag}_kernel_stats.csv")))
+krow = [r for r in stats if a.kernel in r["Name"]][0]
+cfg = bench["config"]
+B, K, N = cfg["reaches_per_gpu"], bench["steps"], cfg["nodes"]
+real = 8 if bench["dtype"] == "f64" else 4
+its = cfg["mean_newton_iterations_per_step"]
+out = {"tag": a.tag, "source": f"rocprofv3 passes of tools/profile.sh {a.tag} " + open(f"{P}/args.txt").read().strip(),
+       "library_sha256": open(f"{P}/library_sha256.txt").read().strip(), "kernel_name": kernel_name[:200],
+       "kernel": cfg["kernel"], "nodes": N, "reaches": B, "levels_in_launch": K, "dtype": bench["dtype"],
+       "mean_newton_iterations_per_step": its,
+       "kernel_stats_avg_ns": float(krow["AverageNs"]), "kernel_stats_calls": int(krow["Calls"]),
+       "bench_kernel_ms": bench["roofline"]["kernel_ms"], "bench_value": bench["value"]}
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    fetch_raw, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
+    mandatory = 4.0 * B * N * real
+    out.update(fetch_bytes_raw_counter=fetch_raw, fetch_bytes_corrected=2 * fetch_raw, write_bytes=write,
+               mandatory_read_bytes=mandatory, mandatory_write_bytes=mandatory,
+               hbm_bytes_per_reach_timestep=(2 * fetch_raw + write) / (B * K),
+               algorithmic_bytes_per_reach_timestep=4 * N * real + 40,
+               traffic_note="rocprofv3 FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B; the kernel's known reads - "
+                            "hk, Qk, hg, Qg once per launch - calibrate it) + WRITE_SIZE, separate passes, per reach-timestep")
+w = vals.get("SQ_WAVES")
+if w and "SQ_INSTS_VALU" in vals:
+    sfx = "F64" if real == 8 else "F32"
+    fl = 64 * (2 * vals[f"SQ_INSTS_VALU_FMA_{sfx}"] + vals[f"SQ_INSTS_VALU_MUL_{sfx}"] + vals[f"SQ_INSTS_VALU_ADD_{sfx}"]
+               + vals[f"SQ_INSTS_VALU_TRANS_{sfx}"])
+    out.update(flops_per_launch=fl, flops_per_reach_iteration=fl / (B * K * its),
+               valu_instructions_per_wave_iteration=vals["SQ_INSTS_VALU"] / w / (K * its),
+               arithmetic_share_of_valu=fl / 64 / (vals["SQ_INSTS_VALU"] + vals[f"SQ_INSTS_VALU_FMA_{sfx}"]) if False else
+               (vals[f"SQ_INSTS_VALU_FMA_{sfx}"] + vals[f"SQ_INSTS_VALU_MUL_{sfx}"] + vals[f"SQ_INSTS_VALU_ADD_{sfx}"]
+                + vals[f"SQ_INSTS_VALU_TRANS_{sfx}"]) / vals["SQ_INSTS_VALU"])
+if "SQ_ACTIVE_INST_VALU" in vals:
+    out.update(valu_active_per_wave_cycle=vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"],
+               insts_per_wave={k[9:].lower(): vals[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM")})
+if "SQ_WAIT_ANY" in vals:
+    out.update(wait_any_share=vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], wait_inst_any_share=vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"])
+json.dump(out, open(f"{D}/{a.tag}.json", "w"), indent=1)
+shutil.copy(f"{P}/bench_trace.json", f"{D}/{a.tag}_bench_under_rocprof.json")
+print(json.dumps({k: v for k, v in out.items() if k not in ("source", "kernel_name", "traffic_note")}, indent=1))
