@@ -7,6 +7,7 @@
 // that needs one fails and says so.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,6 +79,7 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
+                          FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true)
@@ -204,6 +206,26 @@ int download(fs_batch *b, double *dst, const void *src, size_t off_elems, size_t
     for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
   }
   return 0;
+}
+
+// The caller's TrapezoidalSection table [FS_GEO_NPARAM][N] plus the rows of what follows from it alone
+// (fs_device.hpp FS_GEOX_*: side-slope roots, bankfull geometry, reciprocal / -1.5-power roughnesses), computed here
+// once in double so that no node evaluation of any Newton iteration has to.
+std::vector<double> extend_table(const double *t, size_t N) {
+  std::vector<double> x((size_t)fs::FS_GEOX_NROWS * N, 0.0);
+  std::memcpy(x.data(), t, (size_t)FS_GEO_NPARAM * N * sizeof(double));
+  auto in = [&](int row, size_t i) { return t[(size_t)row * N + i]; };
+  for (size_t i = 0; i < N; ++i) {
+    const double b = in(FS_GEO_B_MAIN, i), m = in(FS_GEO_M_MAIN, i), hbf = in(FS_GEO_H_BANKFULL, i), mfp = in(FS_GEO_M_FP, i);
+    const double sm = std::sqrt(1.0 + m * m), Tb = b + 2.0 * m * hbf;
+    const double nm = in(FS_GEO_N_MAIN, i), nl = in(FS_GEO_N_LEFT, i), nr = in(FS_GEO_N_RIGHT, i);
+    auto put = [&](int row, double v) { x[(size_t)row * N + i] = v; };
+    put(fs::FS_GEOX_SM, sm); put(fs::FS_GEOX_SFP, std::sqrt(1.0 + mfp * mfp)); put(fs::FS_GEOX_TB, Tb);
+    put(fs::FS_GEOX_AM, (b + Tb) / 2.0 * hbf); put(fs::FS_GEOX_PM, b + 2.0 * hbf * sm);
+    put(fs::FS_GEOX_RNM, nm > 0 ? 1.0 / nm : 0.0); put(fs::FS_GEOX_KM15, nm > 0 ? std::pow(nm, -1.5) : 0.0);
+    put(fs::FS_GEOX_KL15, nl > 0 ? std::pow(nl, -1.5) : 0.0); put(fs::FS_GEOX_KR15, nr > 0 ? std::pow(nr, -1.5) : 0.0);
+  }
+  return x;
 }
 
 // level 0 of every array from one (h, Q) pair per reach
@@ -392,7 +414,10 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
   if (!b || !table) return fail("fs_batch_set_geometry_table: null argument");
   if (b->d.section_mode != FS_SEC_TABLE) return fail("fs_batch_set_geometry_table: batch was created with another section_mode");
   FS_ON_DEVICE(b);
-  if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * b->d.n_nodes)) return -1;
+  {
+    const std::vector<double> x = extend_table(table, b->d.n_nodes);
+    if (upload(b, &b->geo_table, x.data(), x.size())) return -1;
+  }
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
   } else if (b->n_override) {
@@ -431,7 +456,10 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
     }
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
   }
-  if (upload(b, &b->geo_table, table, (size_t)FS_GEO_NPARAM * N)) return -1;
+  {
+    const std::vector<double> x = extend_table(table, N);
+    if (upload(b, &b->geo_table, x.data(), x.size())) return -1;
+  }
   if (b->poly_x) { (void)hipFree(b->poly_x); b->poly_x = nullptr; }
   if (b->poly_z) { (void)hipFree(b->poly_z); b->poly_z = nullptr; }
   if (upload(b, &b->poly_x, xt.data(), P * N) || upload(b, &b->poly_z, zt.data(), P * N) ||

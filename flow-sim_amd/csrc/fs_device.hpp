@@ -159,10 +159,20 @@ template <typename R> struct NodeTerms {
   R rT;   // 1 / T: the continuity row's dh coefficient is T/(2dt) on both nodes (preissmann.py:431-447), its reciprocal scales
 };        // the node's momentum entries into the characteristic-like unknowns of the solve (below)
 
-// trapezoidal section parameters at one node (cross_section.py:569-613)
+// rows the library appends to the caller's FS_GEO_* table on upload (fs_abi.hip: extend_table): geometry-only quantities
+enum { FS_GEOX_SM = FS_GEO_NPARAM, FS_GEOX_SFP, FS_GEOX_TB, FS_GEOX_AM, FS_GEOX_PM, FS_GEOX_RNM, FS_GEOX_KM15, FS_GEOX_KL15,
+       FS_GEOX_KR15, FS_GEOX_NROWS };
+
+// trapezoidal section parameters at one node (cross_section.py:569-613) ...
 template <typename R> struct SecParams {
   R z, b, m, nm, nl, nr, hbf, bl, br, mfp, curv;
   bool compound;
+  // ... and what follows from them alone (a lane's nodes never change during a launch; the table modes read these from
+  // rows the library appends to the caller's table on upload, sec_derive() computes them for single sections):
+  R sm, sfp;          // sqrt(1 + m_main^2), sqrt(1 + m_fp^2): wetted perimeter of the side slopes
+  R Tb, Am, Pm;       // bankfull top width, area and wetted perimeter of the main channel (cross_section.py:660-674)
+  R rnm;              // 1 / n_main
+  R km15, kl15, kr15; // n^-1.5 of the main channel and the two floodplains (Horton-Einstein sum, cross_section.py:741-754)
 };
 
 // Rectangular prismatic fast path: A = b h, P = b + 2h, T = b (cross_section.py:636-639).
@@ -230,7 +240,7 @@ template <typename R> __device__ __forceinline__ R p32_(R x) { return x > R(0) ?
 // conveyance of a single sub-section, hydraulics.py:15-26
 template <typename R> __device__ __forceinline__ R conv_(R A, R n, R Rh) { return A * p23_(Rh) * frcp(n); }
 
-template <typename R> struct GeneralProps { R A, P, Rh, T, rT, K, neq, dRdA, dKdA, y13; };
+template <typename R> struct GeneralProps { R A, rA, P, Rh, T, rT, K, rK, neq, dRdA, dKdA, dKdA_K, y13; };
 
 // General trapezoid family (rectangle / simple / compound), straight from the reference including
 // the over-bank area inconsistency and the frozen-n_eq dK/dA.  Kept out of line: it is
@@ -252,54 +262,64 @@ template <typename R> struct GeneralProps { R A, P, Rh, T, rT, K, neq, dRdA, dKd
 #else
 #define FS_GEN_ATTR __noinline__
 #endif
+// x^-1.5 for x > 0
+template <typename R> __device__ __forceinline__ R pm15_(R x) { const R r = frsq(x); return r * r * r; }
+
+// the geometry-only members of SecParams from the others (single sections: uniform-geometry modes, post-processing)
+template <typename R> __device__ __forceinline__ void sec_derive(SecParams<R> &s) {
+  s.sm = sqrt_(R(1) + s.m * s.m); s.sfp = sqrt_(R(1) + s.mfp * s.mfp);
+  s.Tb = s.b + R(2) * s.m * s.hbf;
+  s.Am = (s.b + s.Tb) / R(2) * s.hbf;                             // :660 (column above omitted)
+  s.Pm = s.b + R(2) * s.hbf * s.sm;
+  s.rnm = R(1) / s.nm;
+  s.km15 = pm15_(s.nm); s.kl15 = s.nl > R(0) ? pm15_(s.nl) : R(0); s.kr15 = s.nr > R(0) ? pm15_(s.nr) : R(0);
+}
+
+// K_i^1.5 of one sub-section, K_i = A_i R_i^(2/3) / n_i (hydraulics.py:15-26):  A_i^2.5 / (P_i n_i^1.5) - one reciprocal
+// root and one reciprocal instead of an x^(2/3), a division by n and an x^1.5
+template <typename R> __device__ __forceinline__ R k15_(R A, R P, R n15) {
+  return (A > R(0) && P > R(0)) ? A * A * fsqrt_pos(A) * frcp(P) * n15 : R(0);
+}
+
 template <typename R>
 __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) {
   GeneralProps<R> g;
   const R d = fmax_(R(0), h);
-  const R sm = fsqrt_pos(R(1) + s.m * s.m);
-  R T = s.b + R(2) * s.m * d;
-  R A = (s.b + T) / R(2) * d;
-  R P = s.b + R(2) * d * sm;
-  R dPdh = R(2) * sm;
+  R T = fma_(R(2) * s.m, d, s.b);
+  R A = R(0.5) * (s.b + T) * d;
+  R P = fma_(R(2) * s.sm, d, s.b);
+  R dPdh = R(2) * s.sm;
   const bool over = s.compound && d > s.hbf;
-  R K;
+  R K = R(0);
   if (over) {
     const R dfp = d - s.hbf;
-    const R Tb = s.b + R(2) * s.m * s.hbf;
-    const R sfp = fsqrt_pos(R(1) + s.mfp * s.mfp);
-    const R A_main = (s.b + Tb) / R(2) * s.hbf;                  // :660 (column above omitted)
-    const R P_main = s.b + R(2) * s.hbf * sm;
-    const R A_l = (s.bl + R(0.5) * s.mfp * dfp) * dfp, P_l = s.bl + dfp * sfp;
-    const R A_r = (s.br + R(0.5) * s.mfp * dfp) * dfp, P_r = s.br + dfp * sfp;
-    A = A_main + A_l + A_r;
-    P = P_main + P_l + P_r;
-    T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
-    dPdh = R(2) * sfp;
-    const R A_m = A_main + Tb * dfp;                             // :694 (column included)
-    const R R_m = P_main > R(0) ? A_m * frcp(P_main) : R(0);
-    const R R_l = P_l > R(0) ? A_l * frcp(P_l) : R(0);
-    const R R_r = P_r > R(0) ? A_r * frcp(P_r) : R(0);
-    const R Kl = conv_(A_l, s.nl, R_l), Km = conv_(A_m, s.nm, R_m), Kr = conv_(A_r, s.nr, R_r);
-    K = p23_(p32_(Kl) + p32_(Km) + p32_(Kr));                        // :753
-  } else {
-    K = R(0);                                                        // set below from Rh
+    const R hm = R(0.5) * s.mfp * dfp;
+    const R A_l = (s.bl + hm) * dfp, P_l = fma_(dfp, s.sfp, s.bl);
+    const R A_r = (s.br + hm) * dfp, P_r = fma_(dfp, s.sfp, s.br);
+    A = s.Am + A_l + A_r;                                           // :660-674 (column above the main channel omitted)
+    P = s.Pm + P_l + P_r;
+    T = (s.bl + s.Tb + s.br) + R(2) * s.mfp * dfp;
+    dPdh = R(2) * s.sfp;
+    const R A_m = fma_(s.Tb, dfp, s.Am);                            // :694 (column included)
+    K = p23_(k15_(A_l, P_l, s.kl15) + k15_(A_m, s.Pm, s.km15) + k15_(A_r, P_r, s.kr15));      // :741-754
   }
-  // divisions are reciprocal (v_rcp_f64 + one Newton step, 2e-15) times multiply: an IEEE fp64 divide is ~14
-  // instructions and this function has a dozen of them
+  // divisions are reciprocal (v_rcp_f64 + one Newton step, 2e-15) times multiply: an IEEE fp64 divide is ~14 instructions
   const R rP = P > R(0) ? frcp(P) : R(0), rT = T > R(0) ? frcp(T) : R(0);
   g.Rh = A * rP;
-  if (!over) {
-    K = conv_(A, s.nm, g.Rh);
-    if (s.compound) K = p23_(p32_(K));                             // the reference's round trip, :747-754
-  }
   const R y13 = g.Rh > R(0) ? rcbrt_pos(g.Rh) : R(0);            // R^(-1/3)
   const R R23 = g.Rh * y13;
-  R neq = s.nm;
-  if (s.compound && A > R(0) && g.Rh > R(0) && K > R(0)) neq = A * R23 * frcp(K);     // :710-739
+  // in bank K = A R^(2/3) / n_main; the reference's round trip (K^1.5)^(2/3) for a compound section in bank (:747-754)
+  // is the identity, and its equivalent n = A R^(2/3) / K (:710-739) is n_main there
+  if (!over) K = A * R23 * s.rnm;
+  g.rK = K > R(0) ? frcp(K) : R(0);
+  g.neq = over ? A * R23 * g.rK : s.nm;
   g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * rT)) * (rP * rP);   // :766-790
-  g.dKdA = A <= R(0) ? R(0)
-                     : (R23 + A * R(2.0 / 3.0) * y13 * g.dRdA) * frcp(neq);                        // :756-764
-  g.A = A; g.P = P; g.T = T; g.rT = rT; g.K = K; g.neq = neq; g.y13 = y13;
+  // dK/dA = (R^(2/3) + (2/3) A R^(-1/3) dR/dA) / n_eq with the frozen n_eq = A R^(2/3) / K (:756-764), so
+  // dK/dA / K = 1/A + (2/3) (P/A) dR/dA: neither K nor n_eq has to be divided by
+  g.rA = A > R(0) ? frcp(A) : R(0);
+  g.dKdA_K = g.rA * fma_(R(2.0 / 3.0) * P, g.dRdA, R(1));
+  g.dKdA = K * g.dKdA_K;
+  g.A = A; g.P = P; g.T = T; g.rT = rT; g.K = K; g.y13 = y13;
   return g;
 }
 
@@ -311,34 +331,38 @@ __device__ FS_BC_ATTR GeneralProps<R> general_props_call(const SecParams<R> s, R
 // (Se, dSe/dA, dSe/dQ).  T = geometric top width, dAdh = what the section reports as dA/dh (the same
 // number for the trapezoid family, a finite difference for polylines), y13 = Rh^(-1/3).
 template <typename R>
-__device__ __forceinline__ void add_curvature(R curv, R A, R T, R dAdh, R neq, R y13, R dRdA, R h, R Q, R &Se,
+__device__ __forceinline__ void add_curvature(R curv, R A, R rA, R T, R rT, R dAdh, R neq, R y13, R dRdA, R h, R Q, R &Se,
                                               R &dSeA, R &eQ) {
   if (curv == R(0)) return;               // ==0 guard for Sc, <=1e-12 guard for its derivatives
-  // every division below is a reciprocal (2e-15) times a multiplication
-  const R rc = frcp(curv);
-  const R rA = frcp(A), rT = frcp(T);
+  // every division below is a reciprocal (2e-15) times a multiplication; rA = 1/A, rT = 1/T come from the caller
   const R V = A > R(1e-6) ? Q * rA : Q * R(1e6);                // Q / max(A, 1e-6), hydraulics.py:155-168
-  const R D = T > R(1e-6) ? A * rT : A * R(1e6);
-  const R Fr = V * frsq(R(kG) * fmax_(D, R(1e-6)));
+  const R D = A * rT;
+  const bool deep = T > R(1e-6) && D > R(1e-6);                  // the clamps of froude_num leave D as it is
+  const R rs = frsq(R(kG) * D);                                  // (gD)^-0.5
+  const R Fr = deep ? V * rs : V * frsq(R(kG) * fmax_(T > R(1e-6) ? D : A * R(1e6), R(1e-6)));
   const R f = R(8) * R(kG) * neq * neq * y13;                   // 8 g / C^2 with C = R^(1/6)/n, :217-229
   const R rsq_f = frsq(f), sq = f * rsq_f;
-  const R num = (R(2.86) * sq + R(2.07) * f) * h * h * Fr * Fr;
-  const R den = (R(0.565) + sq) * rc * rc;
-  const R rden = frcp(den);
+  const R hF = h * Fr, hF2 = hF * hF;                            // h^2 Fr^2
+  const R poly = fma_(R(2.86), sq, R(2.07) * f);
+  const R num = poly * hF2;
+  const R c2 = curv * curv;
+  const R r0 = frcp(R(0.565) + sq);
+  const R rden = c2 * r0;                                        // 1 / ((0.565 + sqrt f) rc^2), rc = 1 / curvature
   Se += num * rden;                                             // :94-117
   if (fabs_(curv) > R(1e-12)) {
+    const R rs3 = rs * rs * rs;                                   // (gD)^-1.5
     const R Vr = Q * rA;
-    const R rs = frsq(R(kG) * (A * rT)), rs3 = rs * rs * rs;    // (gD)^-0.5, (gD)^-1.5
-    const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * rT + (-Q * rA * rA) * rs;
+    const R dFrA = R(-0.5) * Vr * rs3 * R(kG) * rT + (-Vr * rA) * rs;
     const R y2 = y13 * y13;
     const R dfA = -(R(8.0 / 3.0)) * R(kG) * neq * neq * (y2 * y2) * dRdA;
     const R half_rsq = R(0.5) * rsq_f;                          // 1 / (2 sqrt f)
-    const R dnum = (R(2.86) * half_rsq * dfA + R(2.07) * dfA) * h * h * Fr * Fr +
-                   (R(2.86) * sq + R(2.07) * f) * (R(2) * h * rT * Fr * Fr + h * h * R(2) * Fr * dFrA);
-    const R dden = (half_rsq * dfA) * rc * rc;
-    dSeA += (dnum * den - num * dden) * (rden * rden) * dAdh;   // :119-137, x dA_dh (cross_section.py:164)
+    const R dnum = fma_(R(2.86) * half_rsq, dfA, R(2.07) * dfA) * hF2 +
+                   poly * (R(2) * h * rT * Fr * Fr + h * h * R(2) * Fr * dFrA);
+    // (dnum den - num dden) / den^2 = (dnum - num dden / den) / den with dden / den = (dfA / (2 sqrt f)) / (0.565 + sqrt f)
+    const R dden_den = half_rsq * dfA * r0;
+    dSeA += fma_(-num, dden_den, dnum) * rden * dAdh;           // :119-137, x dA_dh (cross_section.py:164)
     const R dFrQ = rA * rs;
-    const R dnumq = (R(2.86) * sq + R(2.07) * f) * h * h * R(2) * Fr * dFrQ;
+    const R dnumq = poly * h * h * R(2) * Fr * dFrQ;
     eQ += dnumq * rden;                                         // :139-153
   }
 }
@@ -347,14 +371,13 @@ template <typename R>
 __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h, R Q) {
   const GeneralProps<R> g = general_props(s, h);
   NodeTerms<R> t;
-  const R rK = frcp(g.K);
-  const R iK2 = rK * rK;
+  const R iK2 = g.rK * g.rK;
   const R aQ = fabs_(Q);
   const R Sf = Q * aQ * iK2;
-  R dSeA = R(-2) * Sf * (g.dKdA * rK);   // per unit area
+  R dSeA = R(-2) * Sf * g.dKdA_K;        // per unit area
   R Se = Sf, eQ = R(2) * aQ * iK2;
-  add_curvature(s.curv, g.A, g.T, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q * frcp(g.A);
+  add_curvature(s.curv, g.A, g.rA, g.T, g.rT, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
+  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q * g.rA;
   t.rT = g.rT;
   return t;
 }

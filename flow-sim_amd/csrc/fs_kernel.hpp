@@ -142,13 +142,13 @@ __device__ __forceinline__ BCDesc<R> pinned(const BCDesc<R> &bc) {
 
 template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   static constexpr bool kConstT = true;      // dA/dh = b everywhere: no per-node top width to keep
-  R b, rb, n, z_us, z_ds, inv_nm1, dz;
+  R b, rb, n, rn, z_us, z_ds, inv_nm1, dz;
   __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
     b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
     n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
     z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach];
     z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
-    rb = R(1) / b;
+    rb = R(1) / b; rn = R(1) / n;
     inv_nm1 = R(1) / R(a.N - 1);
     dz = (z_ds - z_us) * inv_nm1;
   }
@@ -165,6 +165,7 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
     SecParams<R> s;
     s.z = bed(node); s.b = b; s.m = R(0); s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
     s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
+    s.sm = R(1); s.rnm = rn; s.sfp = R(1); s.Tb = b; s.Am = R(0); s.Pm = b; s.km15 = s.kl15 = s.kr15 = R(0);   // (not compound: unused)
     return s;
   }
   template <int BCK, int SIDE>
@@ -180,10 +181,11 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
 
 template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   static constexpr bool kConstT = false;
-  R b, m, sm2, n, z_us, z_ds, inv_nm1, dz;
+  R b, m, sm2, n, rn, z_us, z_ds, inv_nm1, dz;
   __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
     b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
     n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
+    rn = R(1) / n;
     z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach];
     z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
     m = a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach];
@@ -203,6 +205,7 @@ template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
     SecParams<R> s;
     s.z = bed(node); s.b = b; s.m = m; s.nm = n; s.nl = n; s.nr = n; s.hbf = R(0);
     s.bl = R(0); s.br = R(0); s.mfp = R(0); s.curv = R(0); s.compound = false;
+    s.sm = R(0.5) * sm2; s.rnm = rn; s.sfp = R(1); s.Tb = b; s.Am = R(0); s.Pm = b; s.km15 = s.kl15 = s.kr15 = R(0);   // (not compound: unused)
     return s;
   }
   template <int BCK, int SIDE>
@@ -216,12 +219,13 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   static constexpr bool kConstT = false;
   const R *tab;
   int N;
-  R n_over;
+  R n_over, rn_over, k15_over;      // per-reach main-channel Manning n (ensembles), its reciprocal and its -1.5 power
   bool has_over;
   __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
     tab = a.geo_table; N = a.N;
     has_over = a.n_override != nullptr;
-    n_over = has_over ? a.n_override[reach] : R(0);
+    n_over = has_over ? a.n_override[reach] : R(1);
+    rn_over = R(1) / n_over; k15_over = pm15_(n_over);
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }      // unused (kConstT == false)
   __device__ __forceinline__ R rT_const() const { return R(0); }
@@ -238,6 +242,9 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
     s.compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
     s.hbf = g(FS_GEO_H_BANKFULL); s.bl = g(FS_GEO_B_FP_LEFT); s.br = g(FS_GEO_B_FP_RIGHT);
     s.mfp = g(FS_GEO_M_FP); s.curv = g(FS_GEO_CURVATURE);
+    s.sm = g(FS_GEOX_SM); s.sfp = g(FS_GEOX_SFP); s.Tb = g(FS_GEOX_TB); s.Am = g(FS_GEOX_AM); s.Pm = g(FS_GEOX_PM);
+    s.rnm = has_over ? rn_over : g(FS_GEOX_RNM); s.km15 = has_over ? k15_over : g(FS_GEOX_KM15);
+    s.kl15 = g(FS_GEOX_KL15); s.kr15 = g(FS_GEOX_KR15);
     return s;
   }
   __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
