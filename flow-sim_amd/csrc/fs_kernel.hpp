@@ -84,10 +84,9 @@
 #endif
 #ifndef FS_PRIME
 #define FS_PRIME 0       // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
-#endif                   // through it: one code instance whatever the compiler does; flagship -3 %: 390 registers instead of 322);
-                         // 0: from a second instance of that code ahead of the loop.  Every multiply-add of the level constants and of the
-                         // uniform-geometry node terms is written as an explicit fma, so the two instances cannot be contracted
-                         // differently and chunked stepping / a restart gives the bits of one launch there too
+#endif                   // through it) instead of from a second instance of that code ahead of the loop.  Not needed for chunked
+                         // stepping == one launch (that holds bit for bit without it, tests/test_gpu_parity.py); costs the
+                         // flagship 3 % (390 registers instead of 322); kept as a switch
 
 namespace fs {
 
@@ -540,6 +539,15 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const R *kcb = &sm.kc[0][0][0] + kco;
+#ifdef FS_DUMPKC
+      if (it == 1 && a.dbg && t == (reach & 63) && level < 12) {      // diagnostic builds: what the first iteration of a level starts from
+        unsigned long long *o = a.dbg + ((size_t)reach * 16 + 4 + level) * 12;
+        for (int i = 0; i < 4; ++i) o[i] = __double_as_longlong((double)sm.kc[i][0][t]);
+        for (int i = 0; i < 4; ++i) o[4 + i] = __double_as_longlong((double)sm.kc[i][M - 1][t]);
+        o[8] = __double_as_longlong((double)h[0]); o[9] = __double_as_longlong((double)Q[0]);
+        o[10] = __double_as_longlong((double)h[M]); o[11] = __double_as_longlong((double)Q[M]);
+      }
+#endif
 
       // ================= 1. boundary rows (boundary.py:56-242) =================
       // lane 0: the upstream row on (dh_0, dQ_0); the lane of node N-1: the downstream row, which is row N-1 of the
@@ -815,7 +823,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         };
         R mj = mR;                                  // m of row M-1
         {
-          const R pM = rc_of(M - 1) - mR;          // node M: p from this lane's last row, m from the next lane
+          // node M: p from this lane's last row, m from the next lane.  rcLast, not a recomputed residual: the next lane's
+          // p of its first row is (this rc) - (this m), and both copies of the shared node must move by the same bits
+          const R pM = rcLast - mR;
           dh[M] = (pM + mB) * i2t_of(M); dQ[M] = (pM - mB) * i2c;
         }
 #pragma unroll

@@ -168,12 +168,13 @@ def test_oracle_agreement_on_fresh_inputs():
 
 
 def test_batch_invariance_bitwise():
-    """Reach i inside a mixed batch == reach i alone, bit for bit, and a rerun gives the same bits.  Chunked stepping
-    agrees with one launch to rounding (1e-13 relative; equal Newton counts): the level constants of a launch's first
-    level are built by a second instance of the code that builds them at every later level (fs_kernel.hpp, FS_PRIME)."""
+    """Reach i inside a mixed batch == reach i alone, a rerun, and chunked stepping == one launch: all bit for bit.
+    (The two lanes that share a node move their copies of it by the same bits - the shared node's p comes from the same
+    two numbers on both sides - so what a launch writes back at its end is exactly what the registers would have
+    carried on.)"""
     from fixture_batch import batch_from_problems
     from synth import rect_problem
-    for N in (1000, 4096):
+    for N in (1000, 4096, 300):
         probs = [rect_problem(N, seed=s, n_steps=4) for s in range(6)]
         with batch_from_problems(probs) as b:
             b.step(4)
@@ -185,14 +186,10 @@ def test_batch_invariance_bitwise():
         assert np.array_equal(h_all, h_again) and np.array_equal(Q_all, Q_again)
         for i in (0, 3, 5):
             with batch_from_problems([probs[i]]) as b1:
-                b1.step(4)
-                h1, Q1 = b1.history_arrays()
-            assert np.array_equal(h1[:, 0], h_all[:, i]) and np.array_equal(Q1[:, 0], Q_all[:, i])
-            with batch_from_problems([probs[i]]) as b1:
                 b1.step(1); b1.step(2); b1.step(1)
                 h1, Q1 = b1.history_arrays()
                 assert np.array_equal(b1.iterations()[:, 0], it_all[:, i])
-            assert rel_err(h1[:, 0], h_all[:, i], 1e-3) <= 1e-13 and rel_err(Q1[:, 0], Q_all[:, i], 1.0) <= 1e-13
+            assert np.array_equal(h1[:, 0], h_all[:, i]) and np.array_equal(Q1[:, 0], Q_all[:, i])
 
 
 def test_steady_state_is_a_fixed_point():
