@@ -23,7 +23,6 @@ FS_LIST_TRAP(FS_DECLARE, double, FS_F64) FS_LIST_TRAP(FS_DECLARE, float, FS_F32)
 FS_LIST_TABLE(FS_DECLARE, double, FS_F64) FS_LIST_TABLE(FS_DECLARE, float, FS_F32)
 FS_LIST_IRREGULAR(FS_DECLARE)
 FS_LIST_NODIAG(FS_DECLARE_NODIAG)
-FS_LIST_ENSEMBLE(FS_DECLARE_ENS)
 #endif
 
 namespace {
@@ -61,17 +60,13 @@ typedef const void *KernelPtr;
 // full   == 1: no per-row selects, valid only for N = 64*W*M
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
-// groups > 0: an ensemble kernel (fs_ensemble.hpp) with that many members per wave, 64 / groups lanes x M rows each
-struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int groups; };   // diag == 0: no history / trace stores
+struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; };   // diag == 0: no history / trace stores
 #define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
   { DT, SEC, M, W, FULL, (int)(BCK), 1, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,          \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>, 0 },
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> },
 #define FS_TABLE_ROW_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                       \
   { DT, SEC, M, W, FULL, (int)(BCK), 0, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>,    \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false>, 0 },
-#define FS_TABLE_ROW_ENS(R, DT, SEC, M, G, BCK)                                                 \
-  { DT, SEC, M, 1, 0, (int)(BCK), 0, &fs_launch_ens<R, SEC, M, G, (int)(BCK)>,                    \
-    (KernelPtr)&fs::ensemble_step_kernel<R, SEC, M, G, (int)(BCK)>, G },
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false> },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -103,7 +98,7 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
-                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG) FS_LIST_ENSEMBLE(FS_TABLE_ROW_ENS)};
+                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
@@ -114,7 +109,7 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
   if (e.dtype != dtype || e.sec != sec) return false;
-  const int cap = e.groups ? (64 / e.groups) * e.M : 64 * e.W * e.M;       // rows of the scalar system: N - 1 cells + the downstream boundary row
+  const int cap = 64 * e.W * e.M;       // rows of the scalar system: N - 1 cells + the downstream boundary row
   if (cap < N) return false;
   if (e.full && N != cap) return false;
   if (!e.diag && need_diag) return false;
@@ -125,10 +120,9 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   return true;
 }
 
-// need_any: the caller needs a kernel of boundary class -1 (iteration budget, host rows).  B: reaches in the batch (an
-// ensemble kernel with G members per wave is only worth it from G reaches on).  FS_KERNEL_ENSEMBLE=0 keeps them out.
+// need_any: the caller needs a kernel of boundary class -1 (iteration budget, host rows)
 const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_diag, std::string *why, bool need_any = false,
-                         bool honour_index = true, int B = 1) {
+                         bool honour_index = true) {
   if (const char *env = honour_index ? std::getenv("FS_KERNEL_INDEX") : nullptr) {      // tests: one specific instantiation or nothing
     const int i = std::atoi(env);
     if (i >= 0 && i < kNumEntries && entry_fits(kEntries[i], dtype, sec, N, usk, dsk, need_diag, need_any)) return &kEntries[i];
@@ -139,24 +133,17 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
   if (const char *env = std::getenv("FS_KERNEL_SHAPE")) std::sscanf(env, "%d,%d", &wantM, &wantW);
   const char *gen = std::getenv("FS_KERNEL_GENERAL");
   const bool general_only = gen && gen[0] == '1';
-  const char *ens = std::getenv("FS_KERNEL_ENSEMBLE");
-  const bool ensembles = !(ens && ens[0] == '0') && !wantM && !general_only;
   const Entry *best = nullptr;
   for (const Entry &e : kEntries) {
     if (!entry_fits(e, dtype, sec, N, usk, dsk, need_diag, need_any)) continue;
-    if (e.groups && (!ensembles || B < e.groups)) continue;
     if (general_only && (!e.diag || e.bck >= 2)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
-    // ensemble kernels first (most members per wave), then smallest capacity; on ties fewer waves per reach, then the more
-    // specific variant
+    // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
     auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
-    bool better;
-    if (!best) better = true;
-    else if (e.groups != best->groups) better = e.groups > best->groups;
-    else better = e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
-                  (e.M == best->M && e.W == best->W && spec > bspec);
-    if (better) best = &e;
+    if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
+        (e.M == best->M && e.W == best->W && spec > bspec))
+      best = &e;
   }
   if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4096 nodes)";
   return best;
@@ -276,7 +263,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
 int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
   std::string why;
   const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
-                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, &why, iter_budget > 0, true, b->d.n_reaches);
+                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, &why, iter_budget > 0);
   if (!k && why.rfind("FS_KERNEL_INDEX", 0) == 0) return fail("fs_batch_step: " + why);
   if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
     return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
@@ -843,7 +830,7 @@ int32_t fs_kernel_table_size(void) { return kNumEntries; }
 int fs_kernel_table_entry(int32_t i, int32_t *out) {
   if (i < 0 || i >= kNumEntries || !out) return fail("fs_kernel_table_entry: index out of range");
   const Entry &e = kEntries[i];
-  out[0] = e.dtype; out[1] = e.sec; out[2] = e.M; out[3] = e.W; out[4] = e.full; out[5] = e.bck; out[6] = e.diag; out[7] = e.groups;
+  out[0] = e.dtype; out[1] = e.sec; out[2] = e.M; out[3] = e.W; out[4] = e.full; out[5] = e.bck; out[6] = e.diag; out[7] = 0;
   return 0;
 }
 

@@ -7,7 +7,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "fs_kernel.hpp"
-#include "fs_ensemble.hpp"
 
 #define FS_BCK(kind) (2 + (kind))
 
@@ -88,26 +87,6 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND)) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
-
-// the ensemble kernels (fs_ensemble.hpp): X(R, DT, SEC, M rows per lane, G members per wave, BCK); N <= (64 / G) * M, batches
-// without history / trace
-template <typename R, int SEC, int M, int G, int BCK>
-void fs_launch_ens(const void *args, int B, hipStream_t st) {
-  const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::ensemble_step_kernel<R, SEC, M, G, BCK>), dim3((B + G - 1) / G), dim3(64), 0, st, a);
-}
-#define FS_LIST_ENSEMBLE(X) \
-  X(double, FS_F64, FS_SEC_TABLE, 4, 2, 0) \
-  X(double, FS_F64, FS_SEC_TABLE, 4, 2, FS_BCK(FS_BC_RATING_BLEND)) \
-  X(double, FS_F64, FS_SEC_TABLE, 4, 4, 0) \
-  X(double, FS_F64, FS_SEC_IRREGULAR, 4, 2, 0) \
-  X(double, FS_F64, FS_SEC_IRREGULAR, 4, 2, FS_BCK(FS_BC_NORMAL_DEPTH))
-#define FS_INSTANTIATE_ENS(R, DT, SEC, M, G, BCK)                                                              \
-  template __global__ void fs::ensemble_step_kernel<R, SEC, M, G, (int)(BCK)>(const fs::KernelArgs<R>);            \
-  template void fs_launch_ens<R, SEC, M, G, (int)(BCK)>(const void *, int, hipStream_t);
-#define FS_DECLARE_ENS(R, DT, SEC, M, G, BCK)                                                                         \
-  extern template __global__ void fs::ensemble_step_kernel<R, SEC, M, G, (int)(BCK)>(const fs::KernelArgs<R>);            \
-  extern template void fs_launch_ens<R, SEC, M, G, (int)(BCK)>(const void *, int, hipStream_t);
 
 // explicit instantiation (fs_part_*.hip) / extern declaration (fs_abi.hip) of one entry
 #define FS_INSTANTIATE(R, DT, SEC, M, W, FULL, BCK)                                                            \

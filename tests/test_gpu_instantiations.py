@@ -39,14 +39,7 @@ TABLE = _table()
 def _id(e):
     sec = ("rect", "trap", "table", "irr")[e["section_mode"]]
     return (f"{e['index']:03d}-{'f64' if e['dtype'] == 0 else 'f32'}-{sec}-{e['cells_per_thread']}x{e['waves_per_reach']}"
-            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-ens%d' % e['members_per_wave'] if e['members_per_wave'] else ''}")
-
-
-def _capacity(e):
-    """rows of the scalar system an entry can take: N - 1 cells + the boundary row"""
-    if e["members_per_wave"]:                       # ensemble kernels: 64 / G lanes x M rows per member
-        return (64 // e["members_per_wave"]) * e["cells_per_thread"]
-    return 64 * e["cells_per_thread"] * e["waves_per_reach"]
+            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-piv' if e['pivoted'] else ''}")
 
 
 def _nodes(e):
@@ -136,7 +129,7 @@ def fixture_problem(name, n_steps=None, member=None):
 def case_for(e):
     """(problem, section mode of the batch, n_main override) for a dispatch-table entry"""
     from flowsim_amd import _abi as A
-    sec, bck, cap = e["section_mode"], e["boundary_class"], _capacity(e)
+    sec, bck, cap = e["section_mode"], e["boundary_class"], 64 * e["cells_per_thread"] * e["waves_per_reach"]
     if sec in (A.SEC_RECT_UNIFORM, A.SEC_TRAP_UNIFORM):
         trap = sec == A.SEC_TRAP_UNIFORM
         if bck >= 2:
@@ -187,7 +180,8 @@ def test_instantiation_against_the_oracle(e, monkeypatch):
     f32 = e["dtype"] == A.F32
     if f32:
         p.tol = 1e-3 if p.N <= 600 else 2e-2      # fp32 cannot resolve ||R|| below ~6e-8 |Q| sqrt(2N) (bench.py uses the same)
-    assert p.N <= _capacity(e), "recipe does not fit the entry"
+    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]
+    assert p.N <= cap, "recipe does not fit the entry"
     ref = oracle_run(p)
     assert ref["status"] == 0
     monkeypatch.setenv("FS_KERNEL_INDEX", str(e["index"]))
