@@ -433,12 +433,12 @@ def test_fp32_rectangular_tracks_the_fp64_reference():
         assert rel_err(Q[:, i], fx["flow"][i], 1.0) <= 5e-4
 
 
-# Reaches of the C5 population (flowsim_amd.synthetic.c5_reach_parameters: seed, global index) on which the
-# fp32 kernels stopped with FS_NAN before the pivot floor existed (fs_device.hpp pivot_det): steep and
-# shallow, uniform flow within a few per cent of the depth h* ~ (5/3) S0 dx at which the unpivoted pivot
-# block {momentum row of cell i, continuity row of cell i+1} is singular.  The first one starts exactly
-# there (det == 0 in fp32 in every cell of the initial state, whatever the build); the others met an
-# exact zero later in the run in one build or another.
+# Reaches of the C5 population (flowsim_amd.synthetic.c5_reach_parameters: seed, global index) on which ROUND 1's
+# elimination - 2x2 blocks in the order of the classical double sweep, no pivoting - met singular pivot blocks: steep
+# and shallow, uniform flow within a few per cent of the depth h* ~ (5/3) S0 dx at which the block {momentum row of
+# cell i, continuity row of cell i+1} is singular (fp32: exact zeros, FS_NAN; it needed a perturbation of the Jacobian).
+# The scalar tridiagonal system the solve works on since round 2 (fs_device.hpp) has no such block; these reaches stay
+# as the regression test of that.
 SINGULAR_PIVOT_REACHES = [(4, 506130), (9, 111108), (3, 154763), (3, 180059), (3, 628857), (6, 722298),
                           (10, 1010160), (20260214, 89004), (20260214, 163455), (9, 848778), (9, 972785)]
 
@@ -455,9 +455,9 @@ def _singular_pivot_problems(N, n_steps, tol):
 
 @pytest.mark.parametrize("shape", ["8,1", "16,4"])
 def test_fp32_rides_through_a_singular_pivot_block(shape, monkeypatch):
-    """fp32, 512 nodes, the whole hydrograph: every reach converges at every level (static pivoting,
-    pivot_det) and stays within 5e-3 of the fp64 run of the same reach (the fp32 mode stops Newton at a
-    residual norm of 1e-3)."""
+    """fp32, 512 nodes, the whole hydrograph: every reach converges at every level - no pivoting, no perturbation -
+    and stays within 5e-3 of the fp64 run of the same reach (the fp32 mode stops Newton at a residual norm of
+    1e-3)."""
     from fixture_batch import batch_from_problems
     monkeypatch.setenv("FS_KERNEL_SHAPE", shape)
     n_steps = 36
@@ -475,8 +475,7 @@ def test_fp32_rides_through_a_singular_pivot_block(shape, monkeypatch):
 
 
 def test_fp64_near_singular_pivot_block_against_the_c_oracle():
-    """The same reaches in fp64 against the partially pivoted banded LU of the C oracle: the unpivoted
-    elimination loses digits of a Newton step there, not of the converged level."""
+    """The same reaches in fp64 against the partially pivoted banded LU of the C oracle."""
     from fixture_batch import batch_from_problems
     from oracle import c_oracle
     probs = _singular_pivot_problems(500, 6, 1e-6)     # 8 cells per lane, ragged, rating-curve instantiation
@@ -516,7 +515,7 @@ def test_trapezoid_reaches_that_fill_the_wave_exactly(N):
 def test_flow_regime_grid_against_the_c_oracle():
     """Bed slope x spatial step x base flow, from backwater-resolved grids (h / h* = 250) to kinematic ones
     (h / h* = 0.02, Froude up to 0.8): the unpivoted tree elimination against partially pivoted LU on both
-    sides of the depth h* where its pivot block changes sign (tools/scan_regimes.py prints the table)."""
+    sides of the depth h* where round 1's pivot block changed sign (tools/scan_regimes.py prints the table)."""
     from fixture_batch import batch_from_problems
     from oracle import c_oracle
     from synth import trap_problem
