@@ -73,20 +73,26 @@
 #ifndef FS_LEVEL_FENCE
 #define FS_LEVEL_FENCE 0     // scheduling fence every k cells of the level-constant pass (0 = none)
 #endif
-#ifndef FS_PIN_SEG
-#define FS_PIN_SEG 1     // keep each merge in its cell's scheduling region (+3 % at M >= 8)
+#ifndef FS_PIN_SEG_F32
+#define FS_PIN_SEG_F32 1 // the same switch for the fp32 instantiations (C5 fp32: +5 % with the pin)
 #endif
+#ifndef FS_PIN_SEG
+#define FS_PIN_SEG 0     // pin the running rows at the end of each cell's scheduling region (round 1's block fold: +3 % at M >= 8; the
+#endif                   // scalar fold has 8 running numbers instead of 10 + a factor and schedules better without: +1.2 %)
 #ifndef FS_PHASE_FENCE
-#define FS_PHASE_FENCE 8   // bit 3: pin the back-substituted updates and fence them off from the acceptance block (+0.9 %, 450 instead of 508 registers); bits 0-2 (other phase boundaries): no gain
+#define FS_PHASE_FENCE 0   // bit 3: pin the back-substituted updates and fence them off from the acceptance block (round 1: +0.9 %; with the
+#endif                     // round-2 solve: fp64 flagship -2.3 %, C5 fp32 +4.5 %: see FS_PHASE_FENCE_F32); bits 0-1 (other phase boundaries): no gain
+#ifndef FS_PHASE_FENCE_F32
+#define FS_PHASE_FENCE_F32 8   // the same switch for the fp32 instantiations (three waves per SIMD at 168 registers: the fence keeps them there)
 #endif
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
 #ifndef FS_PRIME
 #define FS_PRIME 0       // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
-#endif                   // through it) instead of from a second instance of that code ahead of the loop.  Not needed for chunked
-                         // stepping == one launch (that holds bit for bit without it, tests/test_gpu_parity.py); costs the
-                         // flagship 3 % (390 registers instead of 322); kept as a switch
+#endif                   // through it) instead of from a second instance of that code ahead of the loop.  Not needed: with
+                         // -ffp-contract=on (Makefile) the two instances compile to the same arithmetic and chunked stepping equals
+                         // one launch bit for bit (tests/test_gpu_parity.py, test_gpu_dropin.py); flagship -5.5 %; kept as a switch
 
 namespace fs {
 
@@ -645,13 +651,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
             seg.u1 = fma_(-seg.u3, R1, seg.u1); seg.ru = fma_(-seg.u3, R3, seg.ru); seg.u3 = -(seg.u3 * R2);
           }
           rcPrev = row.rc;
-#if FS_PIN_SEG
           // the running rows must exist here: keeps row c's elimination inside cell c's scheduling region
-          // (otherwise the eliminations sink below the last fence and every cell's coefficients are parked)
           // (long chunks only: with M <= 4 the cells' node terms interleave profitably, measured on C4)
-          if (M >= 8)
+          if constexpr (M >= 8 && (sizeof(R) == 4 ? FS_PIN_SEG_F32 : FS_PIN_SEG) != 0)
             asm volatile("" :: "v"(seg.u1), "v"(seg.u3), "v"(seg.ru), "v"(seg.d1), "v"(seg.d2), "v"(seg.d3), "v"(seg.rd), "v"(rcPrev));
-#endif
           L = Rn; i2tL = i2tR;
 #if FS_CELL_FENCE
           if ((c % FS_CELL_FENCE) == FS_CELL_FENCE - 1) __builtin_amdgcn_sched_barrier(0);
@@ -839,11 +842,12 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         dh[0] = (pL + mA) * i2t_of(0); dQ[0] = (pL - mA) * i2c;
       }
       FS_T(6);
-#if FS_PHASE_FENCE & 8
+      if constexpr (((sizeof(R) == 4 ? FS_PHASE_FENCE_F32 : FS_PHASE_FENCE) & 8) != 0) {
 #pragma unroll
-      for (int j = 1; j < M; ++j) asm volatile("" : "+v"(dh[j]), "+v"(dQ[j]));
-      __builtin_amdgcn_sched_barrier(0);
-#elif FS_PHASE_FENCE & 1
+        for (int j = 1; j < M; ++j) asm volatile("" : "+v"(dh[j]), "+v"(dQ[j]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#if FS_PHASE_FENCE & 1
       __builtin_amdgcn_sched_barrier(0);
 #endif
       }   // !prime

@@ -272,6 +272,29 @@ def test_api_misuse_is_reported_not_computed():
     with PreissmannBatch(1, 40, 6) as nb:
         with pytest.raises(E):
             nb.history_arrays()                    # no FS_FLAG_HISTORY on this batch
+        with pytest.raises(E, match="FS_SEC_TABLE or FS_SEC_IRREGULAR"):
+            nb.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_HOST_ROW))       # host rows: table / polyline modes only
+        with pytest.raises(E, match="no field requested|without FS_FLAG_HISTORY"):
+            nb.derive_device(0, 2, fields=0)
+    # the one-iteration-per-launch entry points (host-evaluated boundary rows)
+    from fixture_batch import batch_from_problems
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "bc_compound_normal.npz"))
+    p = O.problem_from_fixture(fx, meta)
+    with batch_from_problems([p], mode="table") as tb:
+        with pytest.raises(E, match="not an FS_BC_HOST_ROW boundary"):
+            tb.set_host_rows(A.DOWNSTREAM, 0.0, 1.0, 0.0)
+        tb.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_HOST_ROW))
+        with pytest.raises(E, match="advances with fs_batch_iterate"):
+            tb.step(1)
+        with pytest.raises(E, match="level out of range"):
+            tb.restart(p.nt, p.h0, p.Q0, p.h0, p.Q0)
+        it = tb.boundary_iterate()
+        assert it.shape == (4, 1) and it[0, 0] == p.h0[0] and it[3, 0] == p.Q0[-1]
+    with batch_from_problems([p], mode="table") as tb:
+        tb.iterate()                               # a level opened with iterate() must be closed with it
+        if tb.level == 0:
+            with pytest.raises(E, match="must be closed with it first"):
+                tb.step(1)
 
 
 def test_eight_wave_shape_on_a_full_width_reach(monkeypatch):
