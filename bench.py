@@ -333,6 +333,19 @@ def main():
 
     st = batch.status()
     its = batch.iterations(Wm + 1, K)
+    if os.environ.get("FS_STAMPS"):          # diagnostic builds (-DFS_STAMP, FS_LIB=...): cycle sums per phase, to stderr
+        import ctypes as C
+        out = np.zeros((B, 16, 12), dtype=np.uint64)
+        lib = A.lib(); lib.fs_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+        assert lib.fs_debug_stamps(batch._h, out.ctypes.data_as(C.c_void_p)) == 0
+        tot_it = batch.iterations(1, Wm + K).sum(axis=0).astype(np.float64)
+        names = ["fold", "bc", "tree-up", "barrier", "cross-wave", "norm+fence", "down+back", "update+loop", "acc:stores",
+                 "acc:hydro", "acc:level-pass", "-"]
+        nw = batch.kernel_info()["waves_per_reach"]
+        per = out[:, :nw, :].astype(np.float64) / np.maximum(tot_it, 1.0)[:, None, None]
+        for w in range(nw):
+            print("wave", w, " ".join("%s=%.0f" % (names[i], per[:, w, i].mean()) for i in range(11)),
+                  "total=%.0f" % per[:, w].sum(axis=1).mean(), file=sys.stderr)
     ok = bool(np.all(st == 0))
     el_t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
     kms_t = torch.tensor([kern_ms], dtype=torch.float64, device=f"cuda:{local}")

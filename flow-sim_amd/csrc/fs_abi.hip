@@ -816,11 +816,11 @@ double fs_batch_last_step_ms(fs_batch *b) {
 int32_t fs_batch_last_launch_count(fs_batch *b) { return b ? b->launches : 0; }
 
 #ifdef FS_STAMP
-// diagnostic builds only: out[B][16][8] cycle sums (waves beyond W are zero)
+// diagnostic builds only: out[B][16][12] cycle sums (waves beyond W are zero)
 int fs_debug_stamps(fs_batch *b, unsigned long long *out) {
   if (!b || !out || !b->dbg) return fail("fs_debug_stamps: not available");
   HIP_TRY(hipStreamSynchronize(b->stream));
-  HIP_TRY(hipMemcpy(out, b->dbg, (size_t)b->d.n_reaches * 16 * 8 * 8, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, b->dbg, (size_t)b->d.n_reaches * 16 * 12 * 8, hipMemcpyDeviceToHost));
   return 0;
 }
 #endif
