@@ -761,7 +761,8 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
     }
     dev[f] = b->derived[f];
   }
-  const dim3 grid((unsigned)((BN + 255) / 256));
+  const size_t per_thread = 16 / b->esz;           // one 16-byte access per thread, level and field
+  const dim3 grid((unsigned)(((BN + per_thread - 1) / per_thread + 255) / 256));
   HIP_TRY(hipEventRecord(b->ev0, b->stream));      // fs_batch_last_step_ms() then reports this kernel
   if (b->d.dtype == FS_F64) {
     fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
@@ -769,14 +770,14 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
                              (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
                              (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
                              (double *)dev[5], (double *)dev[6], (double *)dev[7]};
-    hipLaunchKernelGGL((fs::derive_fields_kernel<double>), grid, dim3(256), 0, b->stream, a);
+    hipLaunchKernelGGL((fs::derive_fields_kernel<double, 2>), grid, dim3(256), 0, b->stream, a);
   } else {
     fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
                             (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
                             (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
                             (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
                             (float *)dev[5], (float *)dev[6], (float *)dev[7]};
-    hipLaunchKernelGGL((fs::derive_fields_kernel<float>), grid, dim3(256), 0, b->stream, a);
+    hipLaunchKernelGGL((fs::derive_fields_kernel<float, 4>), grid, dim3(256), 0, b->stream, a);
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(b->ev1, b->stream));

@@ -945,9 +945,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
 
 // ---------------------------------------------------------------------------------------------
-// Post-processing (reference: Solver.prepare_results, solver.py:65-127).  One thread per
-// (reach, node) walks the stored levels: consecutive threads touch consecutive nodes, every
-// load / store is coalesced, 16 B in and up to 56 B out per element - a plain HBM-bound stream.
+// Post-processing (reference: Solver.prepare_results, solver.py:65-127).  One thread per V consecutive
+// (reach, node) elements walks the stored levels: 16-byte loads / stores (V = 2 doubles, 4 floats), consecutive
+// threads on consecutive elements, 16 B in and up to 56 B out per element - a plain HBM-bound stream.
 // ---------------------------------------------------------------------------------------------
 template <typename R> struct DeriveArgs {
   int32_t B, N, first, n, section_mode;
@@ -958,61 +958,103 @@ template <typename R> struct DeriveArgs {
   R *level, *area, *top, *froude, *vel, *cel, *amp, *peak;   // [n][B][N] (peak: [B][N]) or nullptr
 };
 
-template <typename R> __global__ void derive_fields_kernel(const DeriveArgs<R> a) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t BN = (size_t)a.B * a.N;
-  if (i >= BN) return;
-  const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
-  SecParams<R> s;
-  PolyNode<R> pnode;
-  pnode.n = 0;
-  if (a.section_mode == FS_SEC_TABLE || a.section_mode == FS_SEC_IRREGULAR) {
-    auto g = [&](int row) { return a.geo_table[(size_t)row * a.N + node]; };
-    s.z = g(FS_GEO_Z_BED); s.b = g(FS_GEO_B_MAIN); s.m = g(FS_GEO_M_MAIN);
-    s.compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
-    s.hbf = g(FS_GEO_H_BANKFULL); s.bl = g(FS_GEO_B_FP_LEFT); s.br = g(FS_GEO_B_FP_RIGHT); s.mfp = g(FS_GEO_M_FP);
-    if (a.section_mode == FS_SEC_IRREGULAR && a.poly_n[node] > 0) {
-      pnode.x = a.poly_x + node; pnode.z = a.poly_z + node; pnode.stride = a.N; pnode.n = a.poly_n[node];
-    }
+template <typename R, int V> struct Pack { typedef R type __attribute__((ext_vector_type(V))); };
+
+// V elements from / to p: one 16-byte access when the thread's elements all exist and the row is aligned (whole)
+template <typename R, int V> __device__ __forceinline__ void load_pack(const R *__restrict__ p, bool whole, int cnt, R (&out)[V]) {
+  if (whole) {
+    const typename Pack<R, V>::type q = *reinterpret_cast<const typename Pack<R, V>::type *>(p);
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = q[e];
   } else {
-    const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
-    const R w2 = R(node) / R(a.N - 1);
-    s.z = z_us * (R(1) - w2) + z_ds * w2;
-    s.b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
-    s.m = a.section_mode == FS_SEC_TRAP_UNIFORM ? a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach] : R(0);
-    s.compound = false; s.hbf = s.bl = s.br = s.mfp = R(0);
+#pragma unroll
+    for (int e = 0; e < V; ++e) out[e] = e < cnt ? p[e] : R(1);
   }
-  const R h0 = a.hist_h[i];                 // depth[0] (amplitude reference, solver.py:96-97)
-  R peak = R(-3.0e38);
+}
+template <typename R, int V> __device__ __forceinline__ void store_pack(R *__restrict__ p, bool whole, int cnt, const R (&in)[V]) {
+  if (whole) {
+    typename Pack<R, V>::type q;
+#pragma unroll
+    for (int e = 0; e < V; ++e) q[e] = in[e];
+    __builtin_nontemporal_store(q, reinterpret_cast<typename Pack<R, V>::type *>(p));     // written once, read by nobody on the device
+  } else {
+#pragma unroll
+    for (int e = 0; e < V; ++e) if (e < cnt) p[e] = in[e];
+  }
+}
+
+template <typename R, int V> __global__ __launch_bounds__(256) void derive_fields_kernel(const DeriveArgs<R> a) {
+  const size_t BN = (size_t)a.B * a.N;
+  const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+  if (i0 >= BN) return;
+  const int cnt = (int)(BN - i0 < (size_t)V ? BN - i0 : (size_t)V);
+  const bool whole = cnt == V && BN % V == 0;        // every level's row of this thread starts on a 16-byte boundary
+  SecParams<R> s[V];
+  PolyNode<R> pnode[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) {
+    const size_t i = i0 + (e < cnt ? e : 0);
+    const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
+    pnode[e].n = 0;
+    if (a.section_mode == FS_SEC_TABLE || a.section_mode == FS_SEC_IRREGULAR) {
+      auto g = [&](int row) { return a.geo_table[(size_t)row * a.N + node]; };
+      s[e].z = g(FS_GEO_Z_BED); s[e].b = g(FS_GEO_B_MAIN); s[e].m = g(FS_GEO_M_MAIN);
+      s[e].compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
+      s[e].hbf = g(FS_GEO_H_BANKFULL); s[e].bl = g(FS_GEO_B_FP_LEFT); s[e].br = g(FS_GEO_B_FP_RIGHT); s[e].mfp = g(FS_GEO_M_FP);
+      if (a.section_mode == FS_SEC_IRREGULAR && a.poly_n[node] > 0) {
+        pnode[e].x = a.poly_x + node; pnode[e].z = a.poly_z + node; pnode[e].stride = a.N; pnode[e].n = a.poly_n[node];
+      }
+    } else {
+      const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
+      const R w2 = R(node) / R(a.N - 1);
+      s[e].z = z_us * (R(1) - w2) + z_ds * w2;
+      s[e].b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
+      s[e].m = a.section_mode == FS_SEC_TRAP_UNIFORM ? a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach] : R(0);
+      s[e].compound = false; s[e].hbf = s[e].bl = s[e].br = s[e].mfp = R(0);
+    }
+  }
+  R h0[V], peak[V];                          // depth[0] (amplitude reference, solver.py:96-97)
+  load_pack<R, V>(a.hist_h + i0, whole, cnt, h0);
+#pragma unroll
+  for (int e = 0; e < V; ++e) peak[e] = R(-3.0e38);
   for (int k = 0; k < a.n; ++k) {
-    const size_t src = (size_t)(a.first + k) * BN + i, dst = (size_t)k * BN + i;
-    const R h = a.hist_h[src], Q = a.hist_Q[src];
-    // area and top width: cross_section.py:623-679 (incl. the over-bank convention)
-    const R d = fmax_(R(0), h);
-    R T = s.b + R(2) * s.m * d;
-    R A = (s.b + T) / R(2) * d;
-    if (s.compound && d > s.hbf) {
-      const R dfp = d - s.hbf, Tb = s.b + R(2) * s.m * s.hbf;
-      A = (s.b + Tb) / R(2) * s.hbf + (s.bl + R(0.5) * s.mfp * dfp) * dfp + (s.br + R(0.5) * s.mfp * dfp) * dfp;
-      T = (s.bl + Tb + s.br) + R(2) * s.mfp * dfp;
+    const size_t src = (size_t)(a.first + k) * BN + i0, dst = (size_t)k * BN + i0;
+    R h[V], Q[V], lev[V], A[V], T[V], Fr[V], vel[V], cel[V], am[V];
+    load_pack<R, V>(a.hist_h + src, whole, cnt, h);
+    load_pack<R, V>(a.hist_Q + src, whole, cnt, Q);
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      // area and top width: cross_section.py:623-679 (incl. the over-bank convention)
+      const SecParams<R> &se = s[e];
+      const R d = fmax_(R(0), h[e]);
+      R Te = se.b + R(2) * se.m * d;
+      R Ae = (se.b + Te) / R(2) * d;
+      if (se.compound && d > se.hbf) {
+        const R dfp = d - se.hbf, Tb = se.b + R(2) * se.m * se.hbf;
+        Ae = (se.b + Tb) / R(2) * se.hbf + (se.bl + R(0.5) * se.mfp * dfp) * dfp + (se.br + R(0.5) * se.mfp * dfp) * dfp;
+        Te = (se.bl + Tb + se.br) + R(2) * se.mfp * dfp;
+      }
+      if (d <= R(0)) { Ae = R(0); Te = R(0); }
+      if (pnode[e].n > 0) poly_area_top(pnode[e], h[e] + se.z, Ae, Te);     // cross_section.py:248-328
+      const R Ve = Q[e] / Ae;
+      lev[e] = h[e] + se.z; A[e] = Ae; T[e] = Te; vel[e] = Ve;
+      {                                        // hydraulics.py:155-168 with its clamps
+        const R Vc = Q[e] / fmax_(Ae, R(1e-6)), D = Ae / fmax_(Te, R(1e-6));
+        Fr[e] = Vc / sqrt_(R(kG) * fmax_(D, R(1e-6)));
+      }
+      cel[e] = Ve + sqrt_(R(kG) * Ae / Te);
+      am[e] = h[e] - h0[e];
+      peak[e] = fmax_(peak[e], am[e]);
     }
-    if (d <= R(0)) { A = R(0); T = R(0); }
-    if (pnode.n > 0) poly_area_top(pnode, h + s.z, A, T);     // cross_section.py:248-328
-    const R V = Q / A;
-    if (a.level) a.level[dst] = h + s.z;
-    if (a.area) a.area[dst] = A;
-    if (a.top) a.top[dst] = T;
-    if (a.froude) {                          // hydraulics.py:155-168 with its clamps
-      const R Vc = Q / fmax_(A, R(1e-6)), D = A / fmax_(T, R(1e-6));
-      a.froude[dst] = Vc / sqrt_(R(kG) * fmax_(D, R(1e-6)));
-    }
-    if (a.vel) a.vel[dst] = V;
-    if (a.cel) a.cel[dst] = V + sqrt_(R(kG) * A / T);
-    const R am = h - h0;
-    if (a.amp) a.amp[dst] = am;
-    peak = fmax_(peak, am);
+    if (a.level) store_pack<R, V>(a.level + dst, whole, cnt, lev);
+    if (a.area) store_pack<R, V>(a.area + dst, whole, cnt, A);
+    if (a.top) store_pack<R, V>(a.top + dst, whole, cnt, T);
+    if (a.froude) store_pack<R, V>(a.froude + dst, whole, cnt, Fr);
+    if (a.vel) store_pack<R, V>(a.vel + dst, whole, cnt, vel);
+    if (a.cel) store_pack<R, V>(a.cel + dst, whole, cnt, cel);
+    if (a.amp) store_pack<R, V>(a.amp + dst, whole, cnt, am);
   }
-  if (a.peak) a.peak[i] = peak;
+  if (a.peak) store_pack<R, V>(a.peak + i0, whole, cnt, peak);
 }
 
 }  // namespace fs

@@ -243,6 +243,39 @@ def test_derived_fields_can_stay_on_the_device():
         assert rel(host["froude_number"][:, 0], fx["derived_froude_number"], 1e-6) <= TOL
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", ["akbari", "example", "gerd"])
+def test_derived_fields_in_batches_of_any_size(name, dtype):
+    """the post-processing kernel moves 16 bytes per access (2 doubles / 4 floats per thread) when the batch's B*N
+    elements allow it and falls back to single elements otherwise: B = 1 .. 4 copies of a reach (N = 30, 21, 121, so both
+    paths and the ragged last thread occur in either precision) give, reach by reach, the bits of the batch of one, and
+    that one the reference's prepare_results arrays"""
+    from fixture_batch import batch_from_problems
+    if dtype == "f32" and name != "akbari":
+        pytest.skip("fp32: the rectangular case only (N = 30: B*N % 4 is 2, 0, 2, 0)")
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    p = O.problem_from_fixture(fx, meta)
+    nlev = 6
+    fields = ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity", "amplitude", "peak_amplitude")
+    ref = None
+    for B in (1, 2, 3, 4):
+        with batch_from_problems([p] * B, dtype=dtype) as b:
+            b.step(nlev - 1)
+            assert np.all(b.status() == 0)
+            d = b.derive(0, nlev)
+        assert set(d) == set(fields)
+        if ref is None:
+            ref = d
+            if dtype == "f64":
+                for f in ("area", "froude_number", "velocity"):
+                    assert rel(d[f][:, 0], fx["derived_" + f][:nlev], 1e-6) <= TOL, f
+        for f in fields:
+            for j in range(B):
+                got = d[f][j] if f == "peak_amplitude" else d[f][:, j]
+                want = ref[f][0] if f == "peak_amplitude" else ref[f][:, 0]
+                assert np.array_equal(got, want), (f, B, j)
+
+
 def test_batches_on_two_devices_in_one_process():
     """every entry point switches to its batch's device and back: a batch on device 1 configured and stepped
     while device 0 is current, next to a batch on device 0"""
