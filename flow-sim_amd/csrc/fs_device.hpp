@@ -132,7 +132,9 @@ template <> struct Parked<float> {
 };
 #endif
 
-template <typename R> __device__ __forceinline__ R fabs_(R x) { return x < R(0) ? -x : x; }
+// |x| as the operand modifier of the instruction that consumes it (a compare-and-select costs four instructions per use)
+__device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
+__device__ __forceinline__ float fabs_(float x) { return __builtin_fabsf(x); }
 template <typename R> __device__ __forceinline__ R fmax_(R a, R b) { return a > b ? a : b; }
 // x^b as exp(b log x) for x > 0 (|error| ~ b |log x| ulp: 1e-15 .. 1e-14 relative, against a parity bar of 1e-8): two
 // libm calls of ~50 instructions instead of pow()'s ~300 with its special cases, once per Newton iteration in the rating row
@@ -153,7 +155,8 @@ template <typename R> struct NodeTerms {
   R A;    // wetted area                         (cross_section.py:623-679)
   R T;    // dA/dh = top width                   (cross_section.py:792-793)
   R Se;   // Sf + Sc                             (channel.py:53-69)
-  R eA;   // (dSe/dA in the reference's mixed convention) * dA/dh      (channel.py:71-87)
+  R eAT;  // (dSe/dA in the reference's mixed convention) * dA/dh / T  (channel.py:71-87; the momentum row's dh entries are
+          // used divided by the node's top width, below)
   R eQ;   // dSe/dQ                              (channel.py:89-105)
   R v;    // Q / A
   R rT;   // 1 / T: the continuity row's dh coefficient is T/(2dt) on both nodes (preissmann.py:431-447), its reciprocal scales
@@ -193,9 +196,10 @@ __device__ __forceinline__ NodeTerms<R> node_terms_rect(R b, R rb, R n, R h, R Q
   const R aQ = fabs_(Q);
   t.A = A;
   t.T = b;
-  t.Se = Q * aQ * iK2;                                             // hydraulics.py:57
-  t.eQ = R(2) * aQ * iK2;                                          // hydraulics.py:92
-  t.eA = R(-2) * t.Se * fma_(R(2.0 / 3.0) * b, rP, R(1)) * rh;  // hydraulics.py:75 times T
+  const R w = aQ * iK2;
+  t.Se = Q * w;                                                    // hydraulics.py:57
+  t.eQ = w + w;                                                    // hydraulics.py:92
+  t.eAT = t.Se * fma_(R(-4.0 / 3.0) * b, rP, R(-2)) * rA;          // hydraulics.py:75 (times T, over T)
   t.v = Q * rA;
   t.rT = rb;
   return t;
@@ -221,10 +225,11 @@ __device__ __forceinline__ NodeTerms<R> node_terms_trap(R b, R m, R sm2, R n, R 
   const R aQ = fabs_(Q);
   t.A = A;
   t.T = T;
-  t.Se = Q * aQ * iK2;
-  t.eQ = R(2) * aQ * iK2;
-  const R f = fma_(R(2.0 / 3.0), fma_(-(sm2 * A * rT), rP, R(1)), R(1));
-  t.eA = R(-2) * t.Se * f * rA * T;
+  const R w = aQ * iK2;
+  t.Se = Q * w;
+  t.eQ = w + w;
+  const R f2 = fma_(R(-4.0 / 3.0), fma_(-(sm2 * A * rT), rP, R(1)), R(-2));      // -2 (1 + (2/3)(...))
+  t.eAT = t.Se * f2 * rA;
   t.v = Q * rA;
   t.rT = rT;
   return t;
@@ -377,7 +382,7 @@ __device__ FS_GEN_ATTR NodeTerms<R> node_terms_general(const SecParams<R> s, R h
   R dSeA = R(-2) * Sf * g.dKdA_K;        // per unit area
   R Se = Sf, eQ = R(2) * aQ * iK2;
   add_curvature(s.curv, g.A, g.rA, g.T, g.rT, g.T, g.neq, g.y13, g.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = g.A; t.T = g.T; t.Se = Se; t.eA = dSeA * g.T; t.eQ = eQ; t.v = Q * g.rA;
+  t.A = g.A; t.T = g.T; t.Se = Se; t.eAT = dSeA; t.eQ = eQ; t.v = Q * g.rA;    // (dSeA T) / T
   t.rT = g.rT;
   return t;
 }

@@ -394,7 +394,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   R i2c = R(0.5) / cq;
   R kap = r2dt * i2c;
   R dtcq = dt * cq;
-  R ghx = g * hth * i2c;                      // g (theta/2) / (2cq)
+  R hx = hth * i2c;                           // (theta/2) / (2cq)
+  R ghth = g * hth;                           // the level constant kc2 carries the factor g as well: g Abar in one fma
+  const R ghthk = g * hthk;
   R ghdt = g * hth * dt;
 
   // ---- unknowns of this lane: nodes s0 .. s0+M (clamped copies beyond the last node) ----
@@ -403,7 +405,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
   // level-k constants of the 4-point stencil from the accepted state (h, Q) of level k:
   //   C = [sumA]/(2dt) + cq*dQ                 + kc0
-  //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + g*(hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)
+  //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + (g*hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)     (kc2 carries g)
   // Node s0 + M is lane + 1's node s0 (both lanes hold bitwise equal copies of its unknowns): with one wave per reach the
   // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding row ever looks at
   // (and discards) unless the reach fills the wave exactly - then lane 63 evaluates its last node itself.
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) {
     auto rol = [](R v) { return dpp_mov<0x134>(v); };     // wave_rol:1
     NodeTerms<R> r;
-    r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eA = rol(first.eA); r.eQ = rol(first.eQ); r.v = rol(first.v);
+    r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eAT = rol(first.eAT); r.eQ = rol(first.eQ); r.v = rol(first.v);
     r.rT = rol(first.rT);
     if (NC >= 64 * M - 1 && lane == 63) r = geo.terms(min(s0 + M, N - 1), hM, QM);
     return r;
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       // explicit fmas only (no a*b + c left to the compiler's choice: see FS_PRIME)
       sm.kc[0][c][t] = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
       sm.kc[1][c][t] = fma_(cqk, fma_(QQ[c + 1], Rn.v, -(QQ[c] * L.v)), -((QQ[c + 1] + QQ[c]) * r2dt));
-      sm.kc[2][c][t] = hthk * sumA;
+      sm.kc[2][c][t] = ghthk * sumA;
       sm.kc[3][c][t] = fma_(cqk, geo.bed_step(s0 + c) + (hh[c + 1] - hh[c]), hthk * (L.Se + Rn.Se));
       L = Rn;
 #if FS_LEVEL_FENCE
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         const R sumA = A0 + A1;
         sm.kc[0][c][t] = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
         sm.kc[1][c][t] = fma_(cqk, fma_(QQ[c + 1], v1, -(QQ[c] * v0)), -((QQ[c + 1] + QQ[c]) * r2dt));
-        sm.kc[2][c][t] = hthk * sumA;
+        sm.kc[2][c][t] = ghthk * sumA;
         sm.kc[3][c][t] = fma_(cqk, geo.bed_step(s0 + c) + (hh[c + 1] - hh[c]), hthk * (Se0 + Se1));
         A0 = A1; Se0 = Se1; v0 = v1;
       }
@@ -607,15 +609,14 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           {
             const R sumA = L.A + Rn.A;
             const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + k0;                            // :220-249
-            const R avgA = hth * sumA + k2;
+            const R gA = fma_(ghth, sumA, k2);                                                    // g Abar
             const R S = cq * (geo.bed_step(s0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + k3;
-            const R gA = g * avgA;
             const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + k1 + gA * S;   // :251-301
             // momentum entries (preissmann.py:496-733) scaled by 1/(2t) of their node (dh) and 1/(2cq) (dQ):
             //   X0 = pm0 dt/T0, Y0 = pm1/(2cq), X1 = sm0 dt/T1, Y1 = sm1/(2cq)
-            const R gAdt = gA * dt, gAx = avgA * ghx, sdt = ghdt * S;
-            const R X0 = fma_(gAdt, L.rT * fma_(hth, L.eA, -cq), fma_(dtcq, L.v * L.v, sdt));       // :558-612
-            const R X1 = fma_(gAdt, Rn.rT * fma_(hth, Rn.eA, cq), fma_(-dtcq, Rn.v * Rn.v, sdt));    // :496-550
+            const R gAdt = gA * dt, gAx = gA * hx, sdt = ghdt * S;
+            const R X0 = fma_(gAdt, fma_(hth, L.eAT, -(cq * L.rT)), fma_(dtcq, L.v * L.v, sdt));      // :558-612
+            const R X1 = fma_(gAdt, fma_(hth, Rn.eAT, cq * Rn.rT), fma_(-dtcq, Rn.v * Rn.v, sdt));    // :496-550
             const R Y0 = fma_(gAx, L.eQ, kap - L.v);                                                 // :677-733
             const R Y1 = fma_(gAx, Rn.eQ, kap + Rn.v);                                               // :619-675
             const R ga = X1 + Y1;

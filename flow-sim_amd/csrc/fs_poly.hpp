@@ -200,7 +200,7 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
   R dSeA = R(-2) * Sf * (dK * rK);
   R Se = Sf, eQ = R(2) * aQ * iK2;
   add_curvature(nd.curv, e.A, frcp(e.A), e.T, frcp(e.T), e.dAdh, e.neq, e.y13, e.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eA = dSeA * e.dAdh; t.eQ = eQ; t.v = Q * frcp(e.A);
+  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eAT = dSeA; t.eQ = eQ; t.v = Q * frcp(e.A);
   t.rT = frcp(e.dAdh);
   return t;
 }
