@@ -547,6 +547,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       int ln = lane;
       asm volatile("" : "+v"(ln));
       const R *kcb = &sm.kc[0][0][0] + kco;
+      // second half of the constants from a base of its own: beyond 64 KB a ds_read has no immediate offset left, and every
+      // one of those loads would come with an address add (32 per iteration in the 4096-node kernels)
+      int kco2 = kco + 2 * M * T;
+      if constexpr (4 * M * T * sizeof(R) > 65536) asm volatile("" : "+v"(kco2));
+      const R *kcb2 = &sm.kc[0][0][0] + kco2;
 #ifdef FS_DUMPKC
       if (it == 1 && a.dbg && t == (reach & 63) && level < 12) {      // diagnostic builds: what the first iteration of a level starts from
         unsigned long long *o = a.dbg + ((size_t)reach * 16 + 4 + level) * 12;
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         R rcPrev = R(0);
 #pragma unroll
         for (int c = 0; c < M; ++c) {
-          const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb[(2 * M + c) * T], k3 = kcb[(3 * M + c) * T];
+          const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb2[(0 * M + c) * T], k3 = kcb2[(1 * M + c) * T];
           const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
           save_terms(c + 1, Rn);
           const R i2tR = dt * Rn.rT;
