@@ -136,6 +136,9 @@ template <> struct Parked<float> {
 __device__ __forceinline__ double fabs_(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float fabs_(float x) { return __builtin_fabsf(x); }
 template <typename R> __device__ __forceinline__ R fmax_(R a, R b) { return a > b ? a : b; }
+// x clamped to [0, 1] in two instructions (v_max / v_min; a NaN comes out as 0 - the callers' other terms keep it)
+__device__ __forceinline__ double clamp01_(double x) { return __builtin_fmin(__builtin_fmax(x, 0.0), 1.0); }
+__device__ __forceinline__ float clamp01_(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 // x^b as exp(b log x) for x > 0 (|error| ~ b |log x| ulp: 1e-15 .. 1e-14 relative, against a parity bar of 1e-8): two
 // libm calls of ~50 instructions instead of pow()'s ~300 with its special cases, once per Newton iteration in the rating row
 #ifndef FS_POW_EXPLOG
@@ -410,9 +413,14 @@ __device__ __forceinline__ R bc_param(const BCDesc<R> &bc, int i, int reach, int
 template <bool RCP, typename R>
 __device__ __forceinline__ R rating_blend(R z, R s0, R buf, R l0, R l1, R l2, R h0, R h1, R h2) {
   R al;
-  if (z >= s0 + buf) al = R(1);
+  if (RCP) {
+    // branch-free: the smoothstep of the clamped argument is exactly 0 / 1 outside the buffer (three evaluations per row,
+    // each with two divergent branches otherwise: 12 % of a C4 iteration went into this row)
+    const R s = clamp01_((z - s0) * frcp(buf));
+    al = R(3) * s * s - R(2) * s * s * s;
+  } else if (z >= s0 + buf) al = R(1);
   else if (z <= s0) al = R(0);
-  else { const R s = RCP ? (z - s0) * frcp(buf) : (z - s0) / buf; al = R(3) * s * s - R(2) * s * s * s; }
+  else { const R s = (z - s0) / buf; al = R(3) * s * s - R(2) * s * s * s; }
   const R lo = l0 + l1 * z + l2 * z * z;
   const R hi = h0 + h1 * z + h2 * z * z;
   return (R(1) - al) * lo + al * hi;
