@@ -62,8 +62,20 @@ class Channel:
         return self.xs_at_node[i].dA_dh(hw=hw)
 
     def Se(self, h, Q, i):
+        """energy slope at node i: friction + transverse circulation (channel.py:53-69)"""
         xs = self.xs_at_node[i]
         return xs.friction_slope(h=h, Q=Q) + xs.curvature_slope(h=h, Q=Q)
+
+    def dSe_dA(self, h, Q, i):
+        """channel.py:71-87.  Mixed convention, reproduced: the friction part is per unit area, the curvature part comes
+        already multiplied by dA/dh (cross_section.py:164) - and the Jacobian multiplies the sum by dA/dh once more."""
+        xs = self.xs_at_node[i]
+        return xs.dSf_dA(h=h, Q=Q) + xs.dSc_dA(h=h, Q=Q)
+
+    def dSe_dQ(self, h, Q, i):
+        """channel.py:89-105"""
+        xs = self.xs_at_node[i]
+        return xs.dSf_dQ(h=h, Q=Q) + xs.dSc_dQ(h=h, Q=Q)
 
     # ---- set-up ------------------------------------------------------------------------------
     def initialize_conditions(self, n_nodes: int) -> None:

@@ -146,9 +146,34 @@ class CrossSection(ABC):
     def z_min(self):
         ...
 
+    @property
+    @abstractmethod
+    def width(self):
+        """total width of the section"""
+
     @abstractmethod
     def properties(self, hw):
+        """(A, P, R, T) at water level hw"""
+
+    @abstractmethod
+    def get_equivalent_n(self, hw):
+        """Manning n that reproduces the section's conveyance with its total A and R"""
+
+    @abstractmethod
+    def conveyance(self, hw):
         ...
+
+    @abstractmethod
+    def dK_dA(self, hw):
+        ...
+
+    @abstractmethod
+    def dR_dA(self, hw):
+        ...
+
+    @abstractmethod
+    def z_at(self, x):
+        """bed elevation at the lateral coordinate x"""
 
     def area(self, hw):
         return self.properties(hw)[0]
@@ -174,12 +199,37 @@ class CrossSection(ABC):
     def friction_slope(self, h, Q):
         return hydraulics.Sf(Q=Q, K=self.conveyance(hw=h + self.z_min))
 
+    def dSf_dA(self, h, Q):
+        """one contiguous wetted channel (cross_section.py:124-131); IrregularSection sums over sub-channels"""
+        hw = h + self.z_min
+        return hydraulics.dSf_dA(Q=Q, K=self.conveyance(hw=hw), dK_dA=self.dK_dA(hw=hw))
+
+    def dSf_dQ(self, h, Q):
+        return hydraulics.dSf_dQ(Q=Q, K=self.conveyance(hw=h + self.z_min))
+
+    def _bend(self, h):
+        """what the three curvature-slope methods hand to hydraulics: level, n_eq, (A, P, R, T), bend radius"""
+        hw = h + self.z_min
+        return hw, self.get_equivalent_n(hw=hw), self.properties(hw), 1.0 / self.curvature
+
     def curvature_slope(self, h, Q):
         if self.curvature == 0:
             return 0.0
-        hw = h + self.z_min
-        A, P, R, T = self.properties(hw)
-        return hydraulics.curvature_slope(h=h, T=T, A=A, Q=Q, n=self.get_equivalent_n(hw), R=R, rc=1.0 / self.curvature)
+        _, n, (A, P, R, T), rc = self._bend(h)
+        return hydraulics.Sc(h=h, T=T, A=A, Q=Q, n=n, R=R, rc=rc)
+
+    def dSc_dA(self, h, Q):
+        """dSc/dA times dA/dh (cross_section.py:154-164: the product is what Channel.dSe_dA adds to dSf/dA)"""
+        if abs(self.curvature) <= 1e-12:
+            return 0.0
+        hw, n, (A, P, R, T), rc = self._bend(h)
+        return hydraulics.dSc_dA(h=h, A=A, Q=Q, n=n, R=R, rc=rc, dR_dA=self.dR_dA(hw=hw), T=T) * self.dA_dh(hw=hw)
+
+    def dSc_dQ(self, h, Q):
+        if abs(self.curvature) <= 1e-12:
+            return 0.0
+        _, n, (A, P, R, T), rc = self._bend(h)
+        return hydraulics.dSc_dQ(h=h, T=T, A=A, Q=Q, n=n, R=R, rc=rc)
 
     def normal_flow(self, hw):
         if self.bed_slope is None or self.bed_slope <= 0.0:
@@ -399,6 +449,33 @@ class IrregularSection(CrossSection):
 
     def friction_slope(self, h, Q):
         return hydraulics.Sf(Q=Q, K=self._channel_K(h + self.z_min))
+
+    def _channel_K_and_slope(self, hw):
+        """(K, dK/dA) of the 1.5-power composite over the sub-channels, None when the surface does not split the section
+        (cross_section.py:394-420): K = S^(2/3), dK/dA = (2/3) S^(-1/3) sum(1.5 K_j^0.5 dK_j/dA), S = sum K_j^1.5"""
+        subs = self.get_subchannels(hw)
+        if len(subs) <= 1:
+            return None
+        S = dS = 0.0
+        for sc in subs:
+            part = IrregularSection(x=sc["x"], z=sc["z"])
+            part.set_roughness_para(self.get_roughness_para())
+            Kj = part.conveyance(hw=hw)
+            S += Kj ** 1.5
+            dS += 1.5 * Kj ** 0.5 * part.dK_dA(hw=hw)
+        return S ** (2.0 / 3.0), (2.0 / 3.0) * S ** (-1.0 / 3.0) * dS
+
+    def dSf_dA(self, h, Q):
+        both = self._channel_K_and_slope(h + self.z_min)
+        if both is None:
+            return super().dSf_dA(h, Q)
+        return hydraulics.dSf_dA(Q=Q, K=both[0], dK_dA=both[1])
+
+    def dSf_dQ(self, h, Q):
+        hw = h + self.z_min
+        if len(self.get_subchannels(hw)) <= 1:
+            return super().dSf_dQ(h, Q)
+        return hydraulics.dSf_dQ(Q=Q, K=self._channel_K(hw))
 
     def z_at(self, x):
         return np.interp(x, self.x, self.z, left=self.z[0], right=self.z[-1])

@@ -9,6 +9,8 @@ kernel runs the Brent iteration itself (FS_BC_STORAGE_CURVE).  The expansion los
 that the reference's Boundary never passes (boundary.py:119-121), so it is always zero there too."""
 import numpy as np
 
+from . import hydraulics
+
 
 class LumpedStorage:
     def __init__(self, solution_boundaries: tuple, surface_area: float = None, min_stage: float = None,
@@ -49,40 +51,83 @@ class LumpedStorage:
             return np.trapezoid([self.area_at(y) for y in ys], ys)
         return 0.5 * (self.area_at(Y2) + self.area_at(Y1)) * (Y2 - Y1)
 
-    def energy_loss(self, entry_area, flow, roughness, hydraulic_radius, A_str=None):
-        """Friction over reservoir_length + K_q V^2/2g (+ expansion when A_str is given); lumped_storage.py:47-74."""
+    # ---- head loss between the storage and the channel end (lumped_storage.py:47-143) ---------------------------------
+    # three parts, each with its two derivatives: friction over reservoir_length, sudden expansion into a stream of area
+    # A_str (zero without one - and the reference's Boundary never passes one), an empirical K_q V^2 / 2g
+    def friction_loss(self, A_ent, Q, n, R):
+        return hydraulics.Sf(A=A_ent, Q=Q, n=n, R=R) * self.reservoir_length
+
+    def dhf_dA(self, A_ent, Q, n, R, dR_dA):
+        return hydraulics.dSf_dA(A=A_ent, Q=Q, n=n, R=R, dR_dA=dR_dA) * self.reservoir_length
+
+    def dhf_dQ(self, A_ent, Q, n, R):
+        return hydraulics.dSf_dQ(A=A_ent, Q=Q, n=n, R=R) * self.reservoir_length
+
+    def dhl_dn(self, A_ent, Q, n, R):
+        """lumped_storage.py:76-81 calls hydraulics.dSf_dn, which the reference's hydraulics module does not define: with
+        capture_losses set the call raises AttributeError there, and so it does here"""
         if not self.capture_losses:
             return 0
-        from . import hydraulics
-        V = flow / entry_area
-        hf = hydraulics.Sf(Q=flow, K=hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)) * self.reservoir_length
-        h_exp = 0 if A_str is None else (1 - entry_area / A_str) ** 2 * V ** 2 / (2 * hydraulics.g)
-        return hf + h_exp + self.K_q * V ** 2 / (2 * hydraulics.g)
+        return hydraulics.dSf_dn(A=A_ent, Q=Q, n=n, R=R) * self.reservoir_length
+
+    @staticmethod
+    def _velocity_head(A_ent, Q):
+        V = Q / A_ent
+        return V, V ** 2 / (2 * hydraulics.g)
+
+    def expansion_loss(self, A_ent, Q, A_str=None):
+        if A_str is None:
+            return 0
+        return (1 - A_ent / A_str) ** 2 * self._velocity_head(A_ent, Q)[1]
+
+    def d_h_exp_dA(self, A_ent, Q, A_str=None):
+        if A_str is None:
+            return 0
+        V, _ = self._velocity_head(A_ent, Q)
+        ratio = 1 - A_ent / A_str
+        return (ratio ** 2 * 2 * V * (-Q / A_ent ** 2) + V ** 2 * 2 * ratio * (-1 / A_str)) / (2 * hydraulics.g)
+
+    def d_h_exp_dQ(self, A_ent, Q, A_str=None):
+        """lumped_storage.py:119-128 differentiates V with -Q/A^2 here (the A-derivative), reproduced"""
+        if A_str is None:
+            return 0
+        V, _ = self._velocity_head(A_ent, Q)
+        return (1 - A_ent / A_str) ** 2 * 2 * V * (-Q / A_ent ** 2) / (2 * hydraulics.g)
+
+    def empirical_loss(self, Q, A_ent):
+        return self.K_q * self._velocity_head(A_ent, Q)[1]
+
+    def d_h_emp_dA(self, A_ent, Q):
+        V, _ = self._velocity_head(A_ent, Q)
+        return self.K_q * 2 * V * (-Q / A_ent ** 2) / (2 * hydraulics.g)
+
+    def d_h_emp_dQ(self, A_ent, Q):
+        V, _ = self._velocity_head(A_ent, Q)
+        return self.K_q * 2 * V * (1. / A_ent) / (2 * hydraulics.g)
+
+    def energy_loss(self, entry_area, flow, roughness, hydraulic_radius, A_str=None):
+        if not self.capture_losses:
+            return 0
+        return (self.friction_loss(A_ent=entry_area, Q=flow, n=roughness, R=hydraulic_radius)
+                + self.expansion_loss(A_ent=entry_area, A_str=A_str, Q=flow) + self.empirical_loss(A_ent=entry_area, Q=flow))
 
     def dhl_dA(self, entry_area, flow, roughness, hydraulic_radius, dR_dA, A_str=None):
-        """d(head loss)/dA of the entry section (lumped_storage.py:76-113); expansion term as energy_loss"""
         if not self.capture_losses:
             return 0
-        from . import hydraulics
-        K = hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)
-        dhf = hydraulics.dSf_dA(Q=flow, K=K, dK_dA=hydraulics.dK_dA(A=entry_area, n=roughness, R=hydraulic_radius, dR_dA=dR_dA)) \
-            * self.reservoir_length
-        V, dV = flow / entry_area, -flow / entry_area ** 2
-        dexp = 0
-        if A_str is not None:
-            Kx = (1 - entry_area / A_str) ** 2
-            dexp = (Kx * 2 * V * dV + V ** 2 * 2 * (1 - entry_area / A_str) * (-1 / A_str)) / (2 * hydraulics.g)
-        return dhf + dexp + self.K_q * 2 * V * dV / (2 * hydraulics.g)
+        return (self.dhf_dA(A_ent=entry_area, Q=flow, n=roughness, R=hydraulic_radius, dR_dA=dR_dA)
+                + self.d_h_exp_dA(A_ent=entry_area, Q=flow, A_str=A_str) + self.d_h_emp_dA(A_ent=entry_area, Q=flow))
 
     def dhl_dQ(self, entry_area, flow, roughness, hydraulic_radius, A_str=None):
-        """d(head loss)/dQ (lumped_storage.py:115-143; its expansion term differentiates V with -Q/A^2)"""
         if not self.capture_losses:
             return 0
-        from . import hydraulics
-        K = hydraulics.conveyance(A=entry_area, n=roughness, R=hydraulic_radius)
-        V = flow / entry_area
-        dexp = 0 if A_str is None else (1 - entry_area / A_str) ** 2 * 2 * V * (-flow / entry_area ** 2) / (2 * hydraulics.g)
-        return hydraulics.dSf_dQ(Q=flow, K=K) * self.reservoir_length + dexp + self.K_q * 2 * V * (1. / entry_area) / (2 * hydraulics.g)
+        return (self.dhf_dQ(A_ent=entry_area, Q=flow, n=roughness, R=hydraulic_radius)
+                + self.d_h_exp_dQ(A_ent=entry_area, Q=flow, A_str=A_str) + self.d_h_emp_dQ(A_ent=entry_area, Q=flow))
+
+    def dA_dY(self, stage):
+        """slope of the area curve at `stage` (np.gradient of the table, no beta shift: lumped_storage.py:159-163)"""
+        if self.area_curve is None:
+            return 0
+        return self.alpha * np.interp(stage, self.area_curve[:, 0], self.area_gradient)
 
     def dY_new_dvol_in(self, duration, vol_in, Y_old, time=None) -> float:
         """d(new stage)/d(inflow volume) = 1 / surface area, 0 on the min_stage floor (lumped_storage.py:37-45)"""

@@ -44,8 +44,30 @@ class PreissmannSolver(Solver):
         super().initialize_t0()
         self.unknowns = self.channel.initial_conditions.flatten()     # x = [h0, Q0, h1, Q1, ...]
 
+    # ---- derivatives of the dry-bed regularisation (preissmann.py:800-872); see Solver.area_at: the branch raises
+    # TypeError in the reference as soon as it is entered (Channel.area_at has no `h` parameter), and here
+    def dAreg_dA(self, i):
+        """d A_reg / dA = (1 + (A - A_min) / sqrt((A - A_min)^2 + eps^2)) / 2"""
+        A_min = self.channel.area_at(i=i, h=self.H_MIN)
+        excess = self.area_at(i=i, regularization=False) - A_min
+        return 0.5 * (1.0 + excess / np.sqrt(excess ** 2 + self.eps ** 2))
+
+    def dQe_dA(self, i):
+        """d(chi Q)/dA with chi = A_reg / (A_reg + A_min): A_min Q A_reg' / (A_reg + A_min)^2"""
+        A_min = self.channel.area_at(i=i, h=self.H_MIN)
+        A_reg = self.area_at(i=i, regularization=True)
+        return A_min * self.flow_at(i=i, chi_scaling=False) * self.dAreg_dA(i=i) / (A_reg + A_min) ** 2
+
+    def dQe_dQ(self, i):
+        """d(chi Q)/dQ = chi"""
+        A_min = self.channel.area_at(i=i, h=self.H_MIN)
+        A_reg = self.area_at(i=i, regularization=True)
+        return A_reg / (A_reg + A_min)
+
     def run(self, tolerance=1e-4, verbose=3, max_iter=100, diagnos=False, dtype="f64") -> None:
         ch = self.channel
+        if self.regularization:
+            self.area_at(k=0, i=0)                 # the reference's first residual evaluation: raises TypeError (Solver.area_at)
         N, nt = self.number_of_nodes, self.number_of_time_levels
         geo = ch.node_geometry
         rect = ("irr_npts" not in geo and np.all(geo["is_compound"] < 0.5) and np.all(geo["m_main"] == 0) and np.all(geo["curvature"] == 0)

@@ -15,8 +15,6 @@ from .channel import Channel
 class Solver(ABC):
     def __init__(self, channel: Channel, time_step, spatial_step, simulation_time, regularization: bool = False,
                  fit_spatial_step: bool = True):
-        if regularization:
-            raise NotImplementedError("regularization is dead code in the reference (SURVEY.md F7) and not carried over")
         self.channel = channel
         self.time_step, self.spatial_step = time_step, spatial_step
         self.time_level = 0
@@ -34,6 +32,7 @@ class Solver(ABC):
         self._solved = False
         self.total_sim_duration = 0
         self.regularization = regularization
+        self.eps = 1e-4
 
     def fit_spatial_step(self):
         self.number_of_nodes = round(self.channel.length / self.spatial_step) + 1
@@ -47,33 +46,62 @@ class Solver(ABC):
         self.depth[0, :] = self.channel.initial_conditions[:, 0]
         self.flow[0, :] = self.channel.initial_conditions[:, 1]
 
-    # ---- accessors (solver.py:244-296) --------------------------------------------------------
+    # ---- accessors (solver.py:244-329) --------------------------------------------------------
+    # The `regularization` / `chi_scaling` arguments select the reference's dry-bed regularisation (a smoothed area floor
+    # and a flow damped by chi = A_reg / (A_reg + A_min)).  That branch cannot run in the reference: it looks the floor
+    # area up with Channel.area_at(i=..., h=...) - a parameter Channel.area_at does not have - and hands A_reg an `eps` it
+    # does not take (solver.py:266, :283, :313), so it raises TypeError at the first evaluation.  The calls are kept as
+    # they are there, and fail the same way; nothing in the kernel depends on them.
+    H_MIN = 1e-4
+
     def _k(self, k):
         return self.time_level if k is None else self.time_level - 1 if k == -1 else k
 
-    def depth_at(self, k=None, i=None):
+    def depth_at(self, k=None, i=None, regularization=None):
         if i is None:
             raise ValueError("Spatial node must be specified.")
         return self.depth[self._k(k), i]
 
-    def flow_at(self, k=None, i=None):
+    def flow_at(self, k=None, i=None, chi_scaling=None):
         if i is None:
             raise ValueError("Spatial node must be specified.")
-        return self.flow[self._k(k), i]
+        k = self._k(k)
+        Q = self.flow[k, i]
+        if self.regularization if chi_scaling is None else chi_scaling:
+            A_reg = self.area_at(k=k, i=i, regularization=True)
+            A_min = self.channel.area_at(i=i, h=self.H_MIN)
+            Q = Q * (A_reg / (A_reg + A_min))
+        return Q
 
-    def water_level_at(self, k=None, i=None):
-        return self.channel.bed_level_at(i=i) + self.depth_at(k=k, i=i)
+    def water_level_at(self, k=None, i=None, regularization=None):
+        return self.channel.bed_level_at(i=i) + self.depth_at(k=k, i=i, regularization=regularization)
 
-    def area_at(self, k=None, i=None):
+    def area_at(self, k=None, i=None, regularization=None):
         if i is None:
             raise ValueError("Spatial node must be specified.")
-        return self.channel.area_at(i=i, hw=self.water_level_at(k=k, i=i))
+        A = self.channel.area_at(i=i, hw=self.water_level_at(k=k, i=i))
+        if self.regularization if regularization is None else regularization:
+            A_min = self.channel.area_at(i=i, hw=self.channel.bed_level_at(i=i) + self.H_MIN)
+            A = self.A_reg(A=A, eps=A_min)
+        return A
 
-    def Se_at(self, k=None, i=None):
-        return self.channel.Se(h=self.depth_at(k=k, i=i), Q=self.flow_at(k=k, i=i), i=i)
+    def Se_at(self, k=None, i=None, regularization=None, chi_scaling=None):
+        return self.channel.Se(h=self.depth_at(k=k, i=i, regularization=regularization),
+                               Q=self.flow_at(k=k, i=i, chi_scaling=chi_scaling), i=i)
 
-    def dA_dh(self, k=None, i=None):
-        return self.channel.dA_dh(i=i, hw=self.water_level_at(k=k, i=i))
+    def dA_dh(self, k=None, i=None, regularization=None):
+        return self.channel.dA_dh(i=i, hw=self.water_level_at(k=k, i=i, regularization=regularization))
+
+    def A_reg(self, A):
+        """smoothed max(A, A_min): A_min + ((A - A_min) + sqrt((A - A_min)^2 + eps^2)) / 2  (solver.py:298-321)"""
+        A_min = self.channel.area_at(i=0, h=self.H_MIN)
+        excess = A - A_min
+        return A_min + 0.5 * (excess + np.sqrt(excess ** 2 + self.eps ** 2))
+
+    def Q_eff(self, Q, A_reg):
+        """flow damped towards zero as the area approaches its floor (solver.py:323-329)"""
+        A_min = self.channel.area_at(i=0, h=self.H_MIN)
+        return Q * (A_reg / (A_reg + A_min))
 
     # ---- post-processing (solver.py:65-127) ----------------------------------------------------------
     def prepare_results(self) -> None:

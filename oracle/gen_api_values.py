@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Known-answer fixture for the host-side public surface: calls the *reference* (cve-mohd/flow-sim, /root/reference,
+read-only) in THIS container and writes inputs + outputs to tests/golden/api_values.json.
+
+TEST INFRASTRUCTURE ONLY (like gen_golden.py).  Each record is a recipe - module, class, constructor arguments, a few
+set-up calls, then a list of method calls with keyword arguments - together with what the reference returned (or the
+name of the exception it raised).  tests/test_api_values.py replays the same recipes on the mirror package
+(src/hydromodel -> flowsim_amd.hydromodel) and compares.
+
+    python oracle/gen_api_values.py
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+
+
+def F(module, name, **kw):
+    return {"module": module, "function": name, "kwargs": kw}
+
+
+def C(module, cls, init, calls, setup=()):
+    return {"module": module, "class": cls, "init": init, "setup": list(setup), "calls": calls}
+
+
+def call(method, **kw):
+    return {"method": method, "kwargs": kw}
+
+
+def section_calls(levels, flows, with_curv=True, extra=()):
+    out = [call("z_min"), call("width")]
+    for hw in levels:
+        out += [call(m, hw=hw) for m in ("properties", "area", "wetted_perimeter", "hydraulic_radius", "top_width", "conveyance",
+                                         "dK_dA", "dR_dA", "dA_dh", "get_equivalent_n", "normal_flow")]
+    for h in [lv for lv in levels]:
+        for Q in flows:
+            d = {"h": h, "Q": Q}
+            out += [call("friction_slope", **d), call("dSf_dA", **d), call("dSf_dQ", **d)]
+            if with_curv:
+                out += [call("curvature_slope", **d), call("dSc_dA", **d), call("dSc_dQ", **d)]
+    out += [call("normal_depth", Q_target=q) for q in (5.0, 80.0, 1e9)]
+    out += [call("z_at", x=x) for x in (-3.0, 0.0, 7.5)]
+    out += [call("get_roughness_para")]
+    return out + list(extra)
+
+
+def recipes():
+    R = []
+    # ---- hydraulics.py: every function, both ways of handing over the conveyance ----
+    geo = dict(A=37.5, n=0.031, R=1.82)
+    for Q in (120.0, -45.0, 0.0):
+        R += [F("hydraulics", "Sf", Q=Q, **geo), F("hydraulics", "Sf", Q=Q, K=1800.0),
+              F("hydraulics", "dSf_dQ", Q=Q, **geo), F("hydraulics", "dSf_dQ", Q=Q, K=1800.0),
+              F("hydraulics", "dSf_dA", Q=Q, dR_dA=0.021, **geo), F("hydraulics", "dSf_dA", Q=Q, K=1800.0, dK_dA=61.0),
+              F("hydraulics", "dSf_dA", Q=Q, K=1800.0, dR_dA=0.021, **geo)]       # K without dK_dA: both are rebuilt
+    R += [F("hydraulics", "conveyance", **geo), F("hydraulics", "dK_dA_", dR_dA=0.021, **geo)]
+    for S0 in (4e-4, -4e-4):
+        R += [F("hydraulics", "normal_flow", bed_slope=S0, area=37.5, roughness=0.031, hydraulic_radius=1.82),
+              F("hydraulics", "normal_flow", bed_slope=S0, K=1800.0),
+              F("hydraulics", "dQn_dA", S_0=S0, dR_dA=0.021, **geo), F("hydraulics", "dQn_dA", S_0=S0, dK_dA=61.0)]
+    bend = dict(h=2.4, T=21.0, A=37.5, Q=120.0, n=0.031, R=1.82, rc=850.0)
+    R += [F("hydraulics", "Sc", **bend), F("hydraulics", "dSc_dQ", **bend), F("hydraulics", "dSc_dA", dR_dA=0.021, **bend),
+          F("hydraulics", "darcey_weisbach_f", n=0.031, R=1.82)]
+    for T, A, Q in ((21.0, 37.5, 120.0), (21.0, 37.5, -45.0), (0.0, 0.0, 3.0), (15.0, 1e-9, 0.5)):
+        R.append(F("hydraulics", "froude_num", T=T, A=A, Q=Q))
+    R += [F("hydraulics", "dFr_dA", T=21.0, A=37.5, Q=120.0), F("hydraulics", "dFr_dQ", T=21.0, A=37.5)]
+    # ---- utility.py ----
+    th = np.linspace(0.0, 1.9, 12)
+    R += [F("utility", "compute_curv", x_coords=(900.0 * np.sin(th)).tolist(), y_coords=(900.0 * (1 - np.cos(th)) + 3 * th ** 2).tolist()),
+          F("utility", "euclidean_norm", vector=[3.0, -4.0, 12.0]), F("utility", "manhattan_norm", vector=[3.0, -4.0, 12.0])]
+    R += [F("utility", "seconds_to_hms", seconds=s) for s in (-5, 0, 59, 3600, 86399, 360000.7)]
+    # ---- cross_section.py ----
+    flows = (60.0, -12.5)
+    R.append(C("cross_section", "TrapezoidalSection", dict(z_bed=100.0, b_main=18.0, m_main=0.0, n_main=0.03, bed_slope=5e-4,
+                                                            curvature=1.2e-3),
+               section_calls((99.5, 100.0, 100.8, 103.1), flows)))
+    R.append(C("cross_section", "TrapezoidalSection", dict(z_bed=12.0, b_main=9.0, m_main=1.5, n_main=0.027, bed_slope=8e-4,
+                                                            curvature=-7e-4),
+               section_calls((12.4, 14.9), flows)))
+    R.append(C("cross_section", "TrapezoidalSection", dict(z_bed=480.0, b_main=120.0, m_main=2.0, n_main=0.028, z_bank=486.0,
+                                                            b_fp_left=300.0, b_fp_right=150.0, m_fp=4.0, n_left=0.05, n_right=0.06,
+                                                            bed_slope=2e-4, curvature=4e-4),
+               section_calls((483.0, 486.0, 486.7, 491.2), (2500.0, -300.0))))
+    R.append(C("cross_section", "TrapezoidalSection", dict(z_bed=3.0, b_main=6.0, m_main=1.0, n_main=0.03),      # no slope, no bend
+               section_calls((4.0,), (10.0,), extra=[call("set_roughness_para", parameters=[0.04, 0.03, 0.05, -2.0, 2.0]),
+                                                     call("get_roughness_para"), call("conveyance", hw=4.0)])))
+    xs = [0.0, 4.0, 9.0, 15.0, 22.0, 26.0, 31.0, 40.0]
+    zs = [8.0, 5.5, 2.0, 1.2, 2.6, 6.1, 4.0, 8.5]            # a levee at x = 26 splits the section between 4.0 and 6.1
+    R.append(C("cross_section", "IrregularSection", dict(x=xs, z=zs, n=0.033, bed_slope=6e-4, curvature=9e-4),
+               section_calls((1.0, 1.9, 3.3, 5.0, 7.4), (35.0, -8.0),
+                             extra=[call("get_subchannels", hw=5.0), call("get_subchannels", hw=7.4)]),
+               setup=[call("set_roughness_para", parameters=[0.05, 0.033, 0.06, 9.0, 24.0])]))
+    R.append(C("cross_section", "IrregularSection", dict(x=[5.0, 0.0, 12.0, 20.0], z=[1.0, 4.0, 0.5, 4.4], n=0.03, bed_slope=1e-3),
+               section_calls((0.9, 2.2, 6.0), (14.0,))))                               # unsorted stations; overtopped at hw = 6
+    # ---- rating_curve.py ----
+    stages = (498.2, 500.0, 503.7)
+    rc_calls = [call(m, stage=s) for s in stages for m in ("discharge", "dQ_dz")] + [call("tostring")]
+    low = [call(m, stage=s) for s in (3.2, 5.0, 8.7) for m in ("discharge", "dQ_dz")] + [call("tostring"),
+                                                                                             call("stage", discharge=700.0, trial_stage=5.0)]
+    R.append(C("rating_curve", "RatingCurve", {}, low, setup=[call("set", type="power", a=42.0, b=1.6)]))
+    R.append(C("rating_curve", "RatingCurve", {}, low, setup=[call("set", type="polynomial", a=3.1, b=20.0, c=11.0)]))
+    R.append(C("rating_curve", "RatingCurve", {}, [call("discharge", stage=1.0), call("dQ_dz", stage=1.0), call("tostring"),
+                                                   call("set", type="cubic", a=1.0, b=2.0), call("set", type="polynomial", a=1.0, b=2.0)]))
+    # set() keeps a stage shift only when it is None (rating_curve.py:12-13): with one, the curve is unusable
+    R.append(C("rating_curve", "RatingCurve", {}, rc_calls, setup=[call("set", type="power", a=42.0, b=1.6, stage_shift=-495.0)]))
+    R.append(C("rating_curve", "RatingCurve", {}, rc_calls, setup=[call("set", type="polynomial", a=3.1, b=-20.0, c=11.0, stage_shift=-495.0)]))
+    R.append(C("rating_curve", "RatingCurve", {}, rc_calls + [call("stage", discharge=900.0, trial_stage=500.0)],
+               setup=[call("fit", discharges=[100.0, 400.0, 900.0, 1700.0, 2600.0], stages=[497.0, 499.0, 501.0, 503.0, 505.0],
+                           stage_shift=-495.0, type="polynomial", scale=True, degree=2)]))
+    R.append(C("rating_curve", "RatingCurve", {}, rc_calls,
+               setup=[call("fit", discharges=[100.0, 400.0, 900.0, 1700.0, 2600.0], stages=[497.0, 499.0, 501.0, 503.0, 505.0],
+                           stage_shift=-495.0, type="power")]))
+    # ---- hydrograph.py ----
+    tab = [[0.0, 50.0], [3600.0, 80.0], [7200.0, 65.0]]
+    times = [call("get_at", time=t) for t in (-10.0, 0.0, 1800.0, 5400.0, 9e4)]
+    R.append(C("hydrograph", "Hydrograph", dict(table={"__ndarray__": tab}), times))
+    R.append(C("hydrograph", "Hydrograph", {}, times[:1]))                                   # undefined: raises
+    R.append(C("hydrograph", "Hydrograph", {}, times, setup=[call("set_table", table={"__ndarray__": tab})]))
+    # ---- lumped_storage.py ----
+    losses = [call("friction_loss", A_ent=55.0, Q=140.0, n=0.03, R=2.1), call("dhf_dA", A_ent=55.0, Q=140.0, n=0.03, R=2.1, dR_dA=0.02),
+              call("dhf_dQ", A_ent=55.0, Q=140.0, n=0.03, R=2.1),
+              call("expansion_loss", A_ent=55.0, Q=140.0), call("expansion_loss", A_ent=55.0, Q=140.0, A_str=300.0),
+              call("d_h_exp_dA", A_ent=55.0, Q=140.0), call("d_h_exp_dA", A_ent=55.0, Q=140.0, A_str=300.0),
+              call("d_h_exp_dQ", A_ent=55.0, Q=140.0), call("d_h_exp_dQ", A_ent=55.0, Q=140.0, A_str=300.0),
+              call("empirical_loss", Q=140.0, A_ent=55.0), call("d_h_emp_dA", A_ent=55.0, Q=140.0), call("d_h_emp_dQ", A_ent=55.0, Q=140.0),
+              call("energy_loss", entry_area=55.0, flow=140.0, roughness=0.03, hydraulic_radius=2.1),
+              call("energy_loss", entry_area=55.0, flow=140.0, roughness=0.03, hydraulic_radius=2.1, A_str=300.0),
+              call("dhl_dA", entry_area=55.0, flow=140.0, roughness=0.03, hydraulic_radius=2.1, dR_dA=0.02, A_str=300.0),
+              call("dhl_dQ", entry_area=55.0, flow=140.0, roughness=0.03, hydraulic_radius=2.1, A_str=300.0),
+              call("dhl_dn", A_ent=55.0, Q=140.0, n=0.03, R=2.1)]
+    curve = [[480.0, 1.0e6], [484.0, 2.5e6], [488.0, 5.5e6], [492.0, 9.0e6], [496.0, 1.3e7]]
+    geom = [call("area_at", stage=s) for s in (479.0, 485.3, 497.0)] + [call("dA_dY", stage=s) for s in (485.3, 490.0)] + \
+           [call("net_vol_change", Y1=484.0, Y2=484.5), call("net_vol_change", Y1=482.0, Y2=495.0), call("net_vol_change", Y1=490.0, Y2=483.0)]
+    R.append(C("lumped_storage", "LumpedStorage", dict(solution_boundaries=[470.0, 500.0], surface_area=2.0e6, min_stage=478.0),
+               losses + [call("area_at", stage=485.0), call("dA_dY", stage=485.0), call("net_vol_change", Y1=484.0, Y2=484.5),
+                         call("mass_balance", duration=600.0, vol_in=9.0e4, Y_old=485.0),
+                         call("mass_balance", duration=600.0, vol_in=-3.0e7, Y_old=485.0),
+                         call("dY_new_dvol_in", duration=600.0, vol_in=9.0e4, Y_old=485.0),
+                         call("dY_new_dvol_in", duration=600.0, vol_in=-3.0e7, Y_old=485.0)],
+               setup=[{"attrs": dict(capture_losses=True, reservoir_length=1500.0, K_q=0.35)}]))
+    R.append(C("lumped_storage", "LumpedStorage", dict(solution_boundaries=None, min_stage=481.0),
+               geom + [call("mass_balance", duration=3600.0, vol_in=4.0e6, Y_old=486.0),
+                       call("dY_new_dvol_in", duration=3600.0, vol_in=4.0e6, Y_old=486.0)] + losses[-5:],
+               setup=[call("set_area_curve", table=curve, alpha=1.1, beta=-0.4)]))
+    return R
+
+
+def jsonable(v):
+    if isinstance(v, dict):
+        return {k: jsonable(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [jsonable(x) for x in v]
+    if isinstance(v, np.ndarray):
+        return jsonable(v.tolist())
+    if isinstance(v, (np.floating, float)):
+        v = float(v)
+        return v if np.isfinite(v) else {"__float__": repr(v)}
+    if isinstance(v, (np.integer, int)) and not isinstance(v, bool):
+        return int(v)
+    return v
+
+
+def decode(v):
+    """kwargs as the callee gets them: {"__ndarray__": [...]} -> np.ndarray"""
+    if isinstance(v, dict):
+        return np.array(v["__ndarray__"], dtype=np.float64) if "__ndarray__" in v else {k: decode(x) for k, x in v.items()}
+    return v
+
+
+def invoke(fn, kwargs):
+    try:
+        return {"value": jsonable(fn(**decode(kwargs)))}
+    except Exception as e:                      # the exception type is part of the behaviour
+        return {"raises": type(e).__name__}
+
+
+def run_recipe(rec, package):
+    mod = importlib.import_module(f"{package}.{rec['module']}")
+    if "function" in rec:
+        return invoke(getattr(mod, rec["function"]), rec["kwargs"])
+    obj = getattr(mod, rec["class"])(**decode(rec["init"]))
+    for st in rec["setup"]:
+        if "attrs" in st:
+            for k, v in st["attrs"].items():
+                setattr(obj, k, v)
+        else:
+            getattr(obj, st["method"])(**decode(st["kwargs"]))
+    out = []
+    for c in rec["calls"]:
+        member = getattr(type(obj), c["method"], None)
+        if isinstance(member, property):
+            out.append({"value": jsonable(getattr(obj, c["method"]))})
+        else:
+            out.append(invoke(getattr(obj, c["method"]), c["kwargs"]))
+    return out
+
+
+def main():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    recs = recipes()
+    for rec in recs:
+        rec["expect"] = run_recipe(rec, "src.hydromodel")
+    path = os.path.join(ROOT, "tests", "golden", "api_values.json")
+    with open(path, "w") as f:
+        json.dump(jsonable(recs), f, indent=0)
+    n = sum(1 if "function" in r else len(r["calls"]) for r in recs)
+    bad = sum(1 for r in recs for e in ([r["expect"]] if "function" in r else r["expect"]) if "raises" in e)
+    print("wrote", path, "-", n, "calls,", bad, "of them raise in the reference")
+
+
+if __name__ == "__main__":
+    main()
