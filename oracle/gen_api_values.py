@@ -147,6 +147,55 @@ def recipes():
                geom + [call("mass_balance", duration=3600.0, vol_in=4.0e6, Y_old=486.0),
                        call("dY_new_dvol_in", duration=3600.0, vol_in=4.0e6, Y_old=486.0)] + losses[-5:],
                setup=[call("set_area_curve", table=curve, alpha=1.1, beta=-0.4)]))
+    # ---- boundary.py: the five kinds, a storage behind a fixed depth (levels 1 and 2), misuse ----
+    def O(rec):
+        return {"__object__": rec}
+    rect = O(C("cross_section", "TrapezoidalSection", dict(z_bed=100.0, b_main=18.0, m_main=0.0, n_main=0.03, bed_slope=5e-4), []))
+    trap = O(C("cross_section", "TrapezoidalSection", dict(z_bed=100.0, b_main=9.0, m_main=1.5, n_main=0.027, bed_slope=-8e-4), []))
+    comp = O(C("cross_section", "TrapezoidalSection", dict(z_bed=100.0, b_main=120.0, m_main=2.0, n_main=0.028, z_bank=106.0,
+                                                           b_fp_left=300.0, b_fp_right=150.0, m_fp=4.0, n_left=0.05, n_right=0.06,
+                                                           bed_slope=2e-4), []))
+    hyd = O(C("hydrograph", "Hydrograph", dict(table={"__ndarray__": tab}), []))
+    power = O(C("rating_curve", "RatingCurve", {}, [], setup=[call("set", type="power", a=42.0, b=1.6)]))
+    state = [dict(depth=2.3, flow=75.0), dict(depth=7.4, flow=-20.0)]
+
+    def rows(extra_res=None, extra_dq=None, times=(1800.0,)):
+        out = []
+        for st in state:
+            for t in times:
+                out += [call("condition_residual", time=t, **st, **(extra_res or {})),
+                        call("df_dh", depth=st["depth"], flow_rate=st["flow"], time=t),
+                        call("df_dQ", depth=st["depth"], flow_rate=st["flow"], time=t, **(extra_dq or {}))]
+        return out + [call("condition_type")]
+    for xs in (rect, trap, comp):
+        R.append(C("boundary", "Boundary", dict(condition="flow_hydrograph", chainage=0.0, bed_level=100.0, hydrograph=hyd),
+                   rows() + [call("condition_residual", depth=2.0, flow=70.0)], setup=[{"attrs": dict(cross_section=xs)}]))
+        R.append(C("boundary", "Boundary", dict(condition="normal_depth", chainage=5e3, bed_level=100.0), rows(),
+                   setup=[{"attrs": dict(cross_section=xs)}]))
+        R.append(C("boundary", "Boundary", dict(condition="rating_curve", chainage=5e3, bed_level=100.0, rating_curve=power), rows(),
+                   setup=[{"attrs": dict(cross_section=xs)}]))
+        R.append(C("boundary", "Boundary", dict(condition="fixed_depth", chainage=5e3, bed_level=100.0, initial_depth=2.5), rows(),
+                   setup=[{"attrs": dict(cross_section=xs)}]))
+        R.append(C("boundary", "Boundary", dict(condition="stage_hydrograph", chainage=0.0, bed_level=40.0, hydrograph=hyd),
+                   rows() + [call("condition_residual", depth=2.0, flow=70.0)], setup=[{"attrs": dict(cross_section=xs)}]))
+    R.append(C("boundary", "Boundary", dict(condition="weir", chainage=0.0), [call("condition_type")]))
+    simple = O(C("lumped_storage", "LumpedStorage", dict(solution_boundaries=[90.0, 120.0], surface_area=2.0e6, min_stage=101.0), []))
+    lossy = O(C("lumped_storage", "LumpedStorage", dict(solution_boundaries=None, min_stage=101.0), [],
+                setup=[call("set_area_curve", table=[[98.0, 1.0e6], [102.0, 2.5e6], [106.0, 5.5e6], [110.0, 9.0e6], [114.0, 1.3e7]],
+                            alpha=1.1, beta=-0.4),
+                       {"attrs": dict(capture_losses=True, reservoir_length=1500.0, K_q=0.35, rating_curve=power)}]))
+    dt = 600            # an integer, as the solver's time_step is in the cases: time // duration indexes a list (boundary.py:104-108)
+    for store in (simple, lossy):
+        for xs in (rect, comp):
+            seq = []
+            for k, st in ((1, state[0]), (1, state[1]), (2, state[0]), (3, state[1])):       # level 1 twice (two Newton iterations), then 2, 3
+                vol = 0.5 * (st["flow"] + 70.0) * dt
+                seq += [call("condition_residual", time=k * dt, duration=dt, vol_in=vol, **st),
+                        call("df_dh", depth=st["depth"], flow_rate=st["flow"], time=k * dt),
+                        call("df_dQ", depth=st["depth"], flow_rate=st["flow"], duration=dt, time=k * dt, vol_in=vol)]
+            seq += [call("condition_residual", **state[0]), call("df_dQ", depth=2.3, flow_rate=75.0)]       # missing arguments
+            R.append(C("boundary", "Boundary", dict(condition="fixed_depth", chainage=5e3, bed_level=100.0, initial_depth=2.5), seq,
+                       setup=[{"attrs": dict(cross_section=xs)}, call("set_lumped_storage", lumped_storage=store)]))
     return R
 
 
@@ -165,38 +214,54 @@ def jsonable(v):
     return v
 
 
-def decode(v):
-    """kwargs as the callee gets them: {"__ndarray__": [...]} -> np.ndarray"""
+def decode(v, package=None):
+    """kwargs as the callee gets them: {"__ndarray__": [...]} -> np.ndarray, {"__object__": recipe} -> an instance built
+    from the same package (a section for a boundary, a rating curve for a storage, ...)"""
     if isinstance(v, dict):
-        return np.array(v["__ndarray__"], dtype=np.float64) if "__ndarray__" in v else {k: decode(x) for k, x in v.items()}
+        if "__ndarray__" in v:
+            return np.array(v["__ndarray__"], dtype=np.float64)
+        if "__object__" in v:
+            return build(v["__object__"], package)
+        return {k: decode(x, package) for k, x in v.items()}
     return v
 
 
-def invoke(fn, kwargs):
+def build(rec, package):
+    mod = importlib.import_module(f"{package}.{rec['module']}")
+    obj = getattr(mod, rec["class"])(**decode(rec["init"], package))
+    for st in rec.get("setup", ()):
+        if "attrs" in st:
+            for k, v in st["attrs"].items():
+                setattr(obj, k, decode(v, package))
+        else:
+            getattr(obj, st["method"])(**decode(st["kwargs"], package))
+    return obj
+
+
+def invoke(fn, kwargs, package=None):
     try:
-        return {"value": jsonable(fn(**decode(kwargs)))}
+        return {"value": jsonable(fn(**decode(kwargs, package)))}
     except Exception as e:                      # the exception type is part of the behaviour
         return {"raises": type(e).__name__}
 
 
 def run_recipe(rec, package):
-    mod = importlib.import_module(f"{package}.{rec['module']}")
     if "function" in rec:
-        return invoke(getattr(mod, rec["function"]), rec["kwargs"])
-    obj = getattr(mod, rec["class"])(**decode(rec["init"]))
-    for st in rec["setup"]:
-        if "attrs" in st:
-            for k, v in st["attrs"].items():
-                setattr(obj, k, v)
-        else:
-            getattr(obj, st["method"])(**decode(st["kwargs"]))
+        mod = importlib.import_module(f"{package}.{rec['module']}")
+        return invoke(getattr(mod, rec["function"]), rec["kwargs"], package)
+    try:
+        obj = build(rec, package)
+    except Exception as e:
+        return [{"raises": type(e).__name__}] * max(len(rec["calls"]), 1)
     out = []
     for c in rec["calls"]:
         member = getattr(type(obj), c["method"], None)
         if isinstance(member, property):
             out.append({"value": jsonable(getattr(obj, c["method"]))})
+        elif "attr" in c:
+            out.append({"value": jsonable(getattr(obj, c["attr"]))})
         else:
-            out.append(invoke(getattr(obj, c["method"]), c["kwargs"]))
+            out.append(invoke(getattr(obj, c["method"]), c["kwargs"], package))
     return out
 
 
