@@ -123,6 +123,37 @@ def test_error_conventions():
     assert not hasattr(rc2, "stage_shift")           # ignored and the attribute only appears for None
 
 
+def test_regularised_branch_fails_like_the_reference():
+    """Solver(regularization=True): the reference builds the solver and raises TypeError at its first area evaluation
+    (solver.py:283: A_reg() is handed an `eps` it does not take; :266 / :313: Channel.area_at has no `h` parameter).  The
+    mirror keeps the accessors and their calls, so the same exceptions come out - run() raises before anything is launched."""
+    from cases.akbari_firoozi import settings as S
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.preissmann import PreissmannSolver
+    us = Boundary(condition='flow_hydrograph', bed_level=S.us_bed if hasattr(S, "us_bed") else 1.0, chainage=0,
+                  hydrograph=Hydrograph(function=lambda t: 100.0))
+    ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=3000.0)
+    ch = Channel(width=20.0, initial_flow=100.0, roughness=0.03, upstream_boundary=us, downstream_boundary=ds,
+                 interpolation_method='steady-state')
+    solver = PreissmannSolver(channel=ch, theta=0.6, time_step=60, spatial_step=100, simulation_time=600, regularization=True)
+    assert solver.regularization is True and solver.eps == 1e-4
+    assert solver.depth_at(k=0, i=0, regularization=True) == solver.depth[0, 0]      # the argument is accepted and unused (:244-249)
+    with pytest.raises(TypeError, match="eps"):
+        solver.area_at(k=0, i=0)
+    with pytest.raises(TypeError, match="eps"):
+        solver.flow_at(k=0, i=0)                      # chi scaling goes through the regularised area first
+    assert solver.flow_at(k=0, i=0, chi_scaling=False) == solver.flow[0, 0]
+    assert solver.area_at(k=0, i=0, regularization=False) == ch.area_at(i=0, hw=solver.water_level_at(k=0, i=0))
+    for broken in (lambda: solver.A_reg(A=5.0), lambda: solver.Q_eff(Q=3.0, A_reg=5.0), lambda: solver.dAreg_dA(i=0),
+                   lambda: solver.dQe_dQ(i=0), lambda: solver.dQe_dA(i=0)):
+        with pytest.raises(TypeError):
+            broken()
+    with pytest.raises(TypeError, match="eps"):
+        solver.run(verbose=0)
+
+
 def test_src_import_paths():
     """`from src.hydromodel.x import Y` as written in the reference's case scripts."""
     from src.hydromodel.boundary import Boundary                      # noqa: F401
