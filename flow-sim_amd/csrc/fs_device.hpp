@@ -145,6 +145,9 @@ __device__ __forceinline__ float clamp01_(float x) { return __builtin_fminf(__bu
 #define FS_POW_EXPLOG 1
 #endif
 __device__ __forceinline__ double pow_(double a, double b) { return (FS_POW_EXPLOG && a > 0.0) ? exp(b * log(a)) : pow(a, b); }
+// the same without the fallback (no branch): NaN for a < 0, as pow() gives for the non-integer exponents of a rating curve
+__device__ __forceinline__ double pow_pos(double a, double b) { return exp(b * log(a)); }
+__device__ __forceinline__ float pow_pos(float a, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(a)); }
 // fp32 is the throughput mode (tolerance 1e-3, no parity bar): x^b as exp2(b log2 x) on the transcendental unit, ~1e-6 relative,
 // instead of libm's powf (165 instructions in the boundary row of every Newton iteration of C5); NaN for x < 0 and 0 for x = 0, b > 0 as powf
 __device__ __forceinline__ float pow_(float a, float b) { return __builtin_amdgcn_exp2f(b * __builtin_amdgcn_logf(a)); }
@@ -612,7 +615,7 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
     } break;
     case FS_BC_RATING_POWER: {
       const R x = p(3) + h + p(2);
-      const R q = p(0) * pow_(x, p(1));                                 // rating_curve.py:59
+      const R q = p(0) * pow_pos(x, p(1));                              // rating_curve.py:59
       r.res = Q - q;
       r.dh = R(0) - p(1) * q * frcp(x);                                 // a b x^(b-1) (:143) from the one pow()
       r.dq = R(1);

@@ -85,6 +85,9 @@
 #ifndef FS_PHASE_FENCE_F32
 #define FS_PHASE_FENCE_F32 8   // the same switch for the fp32 instantiations (three waves per SIMD at 168 registers: the fence keeps them there)
 #endif
+#ifndef FS_FLAT_BC
+#define FS_FLAT_BC 1     // kernels compiled for a boundary pair evaluate the two rows in every lane, without a branch (below)
+#endif
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
@@ -360,6 +363,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   // Short general-section kernels keep (A, Se, Q/A) of every node of the current fold in LDS: if the iterate is accepted they
   // are the node terms of level k, and the level constants of level k+1 come from them instead of from another pass over the
   // sections (1 of 6 section passes of the polyline ensemble, 1 of 11 of C4)
+  constexpr bool kFlatBC = FS_FLAT_BC && BCK >= 2 && sizeof(R) == 8 && SEC == FS_SEC_TRAP_UNIFORM;   // measured: C5 fp64 +1.5 %; flagship -1.5 %, C4 -7 %, polyline -1.3 %
   constexpr bool kSaveTerms = FS_SAVE_TERMS && !Geometry<R, SEC>::kConstT && (M <= 2 || (sizeof(R) == 8 && M <= FS_SAVE_TERMS_MAXM_F64));
   __shared__ Smem<R, M, W, kSaveTerms> sm;
 
@@ -568,6 +572,26 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       BCRow<R> Urow, Drow;
       Drow.dh = R(1); Drow.dq = R(0); Drow.res = R(0);
       R nrm2 = R(0);
+      if constexpr (kFlatBC) {
+        // Boundary kinds fixed at compile time: EVERY lane evaluates both rows, on its own numbers, as straight-line code;
+        // only lane 0 / the lane of node N-1 keep what comes out.  A wave executes a divergent branch for one lane at the
+        // price of all 64 anyway - but a branch is a block of its own, and the row's dependent chain (a pow, a conveyance)
+        // then runs alone at dependent-issue latency ahead of the fold (10 - 16 % of an iteration of the one-wave-per-SIMD
+        // kernels); as straight-line code it is scheduled into the first cell's independent work.
+        R dummy = R(0), YnewAll = Yprev;
+        int fU = 0, fD = 0;
+        Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &fU);
+        R hD = h[0], QD = Q[0];
+#pragma unroll
+        for (int j = RAGGED ? 1 : M - 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+        Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &YnewAll, &fD);
+        const bool isD = t == tD;
+        nrm2 = (t == 0 ? Urow.res * Urow.res : R(0)) + (isD ? Drow.res * Drow.res : R(0));
+        if (isD) {
+          Ynew = YnewAll;
+          if (fD) sm.xflag[parity] = fD;
+        }
+      } else {
       if (t == 0) {
         R dummy; int flag = 0;
         Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
@@ -581,6 +605,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
         nrm2 += Drow.res * Drow.res;
         if (flag) sm.xflag[parity] = flag;
+      }
       }
       FS_T(1);
 
