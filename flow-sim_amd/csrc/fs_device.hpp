@@ -589,11 +589,16 @@ __host__ __device__ constexpr bool bc_is_storage(int kind) { return kind == FS_B
 // k-1; level: k.  Ynew returns the storage stage implied by this evaluation (boundary.py:126-131).
 // WITH_SC = false compiles the general storage row out (kernels of boundary class 0, fs_kernel.hpp): it is the one
 // row with an out-of-line call (the Brent iteration), which costs every caller 90-130 registers and its scratch.
+// The parameters of the closed-form kinds (up to FS_BC_STORAGE) are read from the kernel's LDS copy (the prologue of
+// preissmann_step_kernel points bc.params there for exactly these kinds): ds_read with immediate offsets.  Through the
+// generic pointer every parameter was a flat load behind an address the compiler kept in (spilled) scalar registers -
+// 4 instructions and a full memory wait per parameter, in a row one lane evaluates while the others wait (C4: +7.7 %).
+template <typename R> using LdsParams = const __attribute__((address_space(3))) R *;
 template <bool WITH_SC = true, typename R>
 __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int level, const SecParams<R> sec,
                                          R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {
   BCRow<R> r;
-  auto p = [&](int i) { return bc_param(bc, i, reach, B); };
+  auto p = [&](int i) { return ((LdsParams<R>)bc.params)[i]; };      // kinds <= FS_BC_STORAGE only (bc_storage_curve reads its own)
   switch (bc.kind) {
     case FS_BC_FLOW_HYDROGRAPH:
       r.res = Q - bc.tgt; r.dh = R(0); r.dq = R(1); break;
@@ -649,13 +654,13 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
     } break;
     case FS_BC_STORAGE_CURVE: {
       if (!WITH_SC) { r.res = R(0); r.dh = R(1); r.dq = R(0); break; }      // never launched (fs_abi.hip: pick_kernel)
-      const R bed = p(FS_SC_BED_LEVEL);
+      const R bed = bc_param(bc, FS_SC_BED_LEVEL, reach, B);             // (this kind's parameters stay in global memory)
       return bc_storage_curve(bc, reach, B, level, entry_props(general_props_call(sec, h)),
                               entry_props(general_props_call(sec, h + bed - sec.z)), h, Q, Qold, dt, Yprev, Ynew, flag);
     }
     case FS_BC_HOST_ROW:
       // the row was evaluated by the caller at this Newton vector (fs_batch_set_host_rows; kernels of class -1 only)
-      if (WITH_SC) { r.dh = p(0); r.dq = p(1); r.res = p(2); }
+      if (WITH_SC) { r.dh = bc_param(bc, 0, reach, B); r.dq = bc_param(bc, 1, reach, B); r.res = bc_param(bc, 2, reach, B); }
       else { r.res = R(0); r.dh = R(1); r.dq = R(0); }
       break;
     default:
@@ -672,7 +677,6 @@ __device__ FS_BC_ATTR BCRow<R> bc_eval(const BCDesc<R> bc, int reach, int B, int
 __host__ __device__ constexpr bool bc_is_light(int kind) { return kind != FS_BC_RATING_POWER && kind < FS_BC_STORAGE_CURVE; }
 
 // lp: this reach's parameters in LDS (typed pointer: ds_read, not a flat load through a generic one)
-template <typename R> using LdsParams = const __attribute__((address_space(3))) R *;
 template <typename R>
 __device__ __forceinline__ BCRow<R> bc_eval_rect(const BCDesc<R> &bc, LdsParams<R> lp, int level, R b, R n, R zsec,
                                                  R h, R Q, R Qold, R dt, R Yprev, R *Ynew, int *flag) {

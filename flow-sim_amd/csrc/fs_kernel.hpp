@@ -303,7 +303,7 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
     const BCDesc<R> bc = pinned<BCK, SIDE>(bc_);
     if (pn[node] > 0 && bc.kind == FS_BC_NORMAL_DEPTH)
-      return bc_normal_depth_poly(poly(node), bc_param(bc, 0, reach, B), bc_param(bc, 1, reach, B), h, Q);
+      return bc_normal_depth_poly(poly(node), ((LdsParams<R>)bc.params)[0], ((LdsParams<R>)bc.params)[1], h, Q);   // (LDS copy, as bc_eval)
     if (BCK != 0 && pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
       const PolyNode<R> nd = poly(node);
       const PolyEval<R> er = poly_eval(nd, poly_whole(nd), nd.zmin + h);
