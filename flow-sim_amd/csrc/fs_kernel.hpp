@@ -112,7 +112,8 @@ namespace fs {
 #define FS_T(i) do { } while (0)
 #endif
 
-template <typename R> __host__ __device__ constexpr R huge_norm() { return sizeof(R) == 8 ? R(1e300) : R(3.0e38); }
+template <typename R> __host__ __device__ constexpr R finite_max() { return sizeof(R) == 8 ? R(1.7976931348623157e308) : R(3.4028234e38); }
+template <typename R> __host__ __device__ constexpr R eps_of() { return sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7); }
 
 template <typename R> struct KernelArgs {
   int32_t B, N, n_steps, level0, max_iter;
@@ -773,12 +774,22 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           if (wave == w) { pL = pw[w]; mR = mw[w]; mAw = ma[w]; mBw = ma[w + 1]; }
       }
       FS_T(4);
-      const R err = sqrt_(tot);                                        // utility.py:20-22
       if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
-      if (!(err == err) || !(err <= huge_norm<R>())) status = FS_NAN;        // NaN or overflow (preissmann.py:135-137)
-      converged = status == FS_OK && err < a.tol;                      // preissmann.py:153
-      if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP)
-        a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
+      // ||R|| = sqrt(tot) (utility.py:20-22) is NaN or beyond the blow-up bound (preissmann.py:135-137) exactly when tot is
+      // not finite (the bound exceeds the root of the largest finite number in either precision)
+      if (!(tot <= finite_max<R>())) status = FS_NAN;
+      bool below;                                                      // ||R|| < tolerance (preissmann.py:153)
+      if (DIAG || M < 8) {               // (the two-rows-per-lane kernels sit on their register cap: the branch below costs C4 19 %)
+        const R err = sqrt_(tot);
+        below = err < a.tol;
+        if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
+      } else {
+        // without a trace to write the root is only needed when tot lies within rounding of tol^2 (the decision must be
+        // the one sqrt() gives, bit for bit: Newton counts are compared with the reference's)
+        const R t2 = a.tol * a.tol, band = R(16) * eps_of<R>() * t2;
+        below = tot < t2 - band ? true : (tot > t2 + band ? false : sqrt_(tot) < a.tol);
+      }
+      converged = status == FS_OK && below;
 
       FS_T(5);
       // ================= 5. separators down the tree, local back-substitution ============
