@@ -92,6 +92,8 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
                           FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 2, 1) FS_ENTRY(double, FS_F64, FS_SEC_IRREGULAR, 2, 1)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
+                          FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER))
+                          FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER))
                           FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
                           FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)};
 #else
