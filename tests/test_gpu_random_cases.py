@@ -90,7 +90,86 @@ def random_problem(seed):
     return p, info
 
 
+def random_table_problem(seed):
+    """non-prismatic channel with compound sections (flood plains the wave reaches in some draws) and bends: width, side
+    slope, bed slope, roughness, bankfull depth and curvature vary along the reach"""
+    from synth import normal_depth_trap
+    rng = np.random.default_rng(880000 + seed)
+    N = int(rng.choice([3, 9, 33, 64, 65, 121, 128, 129, 200, 256, 257, 400, 513]))
+    x = np.linspace(0.0, 1.0, N)
+    smooth = lambda lo, hi: lo + (hi - lo) * (0.5 + 0.5 * np.sin(2 * np.pi * (rng.uniform(0.3, 1.5) * x + rng.uniform())))
+    b0 = float(np.exp(rng.uniform(np.log(8.0), np.log(300.0))))
+    b = b0 * smooth(0.85, 1.15)
+    m = smooth(*sorted(rng.uniform(0.5, 2.5, 2)))
+    nm = smooth(*sorted(rng.uniform(0.02, 0.045, 2)))
+    S0 = float(np.exp(rng.uniform(np.log(1e-4), np.log(2e-3))))
+    dx = float(np.exp(rng.uniform(np.log(100.0), np.log(1500.0))))
+    dt = float(np.exp(rng.uniform(np.log(120.0), np.log(3600.0))))
+    theta = float(rng.uniform(0.55, 1.0))
+    q = float(np.exp(rng.uniform(np.log(0.3), np.log(5.0))))
+    Qb = q * b0
+    hn = normal_depth_trap(b0, float(m.mean()), float(nm.mean()), S0, Qb)
+    geo = {k: np.zeros(N) for k in O.GEO_KEYS}
+    geo["b_main"], geo["m_main"], geo["n_main"] = b, m, nm
+    geo["n_left"] = nm * rng.uniform(1.2, 2.0); geo["n_right"] = nm * rng.uniform(1.2, 2.0)
+    geo["z_bed"] = S0 * (N - 1) * dx * (1 - x) + 0.05 * hn * np.sin(6 * np.pi * x)
+    geo["is_compound"][:] = 1.0
+    geo["h_bf"] = hn * smooth(*sorted(rng.uniform(0.9, 2.2, 2)))          # some nodes over bank from the start, some never
+    geo["b_fp_l"] = b * rng.uniform(0.5, 4.0); geo["b_fp_r"] = b * rng.uniform(0.5, 4.0)
+    geo["m_fp"][:] = rng.uniform(2.0, 6.0)
+    geo["curvature"] = rng.uniform(0.0, 2e-3) * np.sin(2 * np.pi * rng.uniform(0.5, 2.0) * x)
+    n_steps = int(rng.integers(2, 6))
+    nt = n_steps + 1
+    amp = float(np.exp(rng.uniform(np.log(0.2), np.log(2.5))))
+    shape = wave(nt, dt, rng.uniform(2, 5) * dt, rng.uniform(6, 12) * dt, amp)
+    ds_k = ("normal", "power", "poly", "fixed", "stage_ds", "blend")[rng.integers(0, 6)]
+    us = O.BC("flow_hydrograph", bed_level=float(geo["z_bed"][0]), target=Qb * shape)
+    zb = float(geo["z_bed"][-1])
+    if ds_k == "normal":
+        ds = O.BC("normal_depth", bed_level=zb, bed_slope=S0)
+    elif ds_k == "fixed":
+        ds = O.BC("fixed_depth", bed_level=zb, initial_depth=hn)
+    elif ds_k == "poly":
+        ds = O.BC("rating_curve", bed_level=zb, rc_type="polynomial", rc=dict(a=0.15 * Qb / hn ** 2, b=0.85 * Qb / hn, c=0.0, shift=-zb))
+    elif ds_k == "power":
+        ds = O.BC("rating_curve", bed_level=zb, rc_type="power", rc=dict(a=Qb / hn ** 1.5, b=1.5, shift=-zb))
+    elif ds_k == "stage_ds":
+        ds = O.BC("stage_hydrograph", bed_level=zb, target=zb + hn * (1.0 + 0.2 * (shape - 1.0) / amp))
+    else:
+        lo = [0.0, 0.9 * Qb / hn, 0.1 * Qb / hn ** 2]
+        ds = O.BC("rating_curve", bed_level=zb, rc_type="blend",
+                  rc=dict(initial_stage=zb + hn, buffer=0.5, low=[lo[0] - lo[1] * zb + lo[2] * zb * zb, lo[1] - 2 * lo[2] * zb, lo[2]],
+                          high=[2 * (lo[0] - lo[1] * zb + lo[2] * zb * zb), 2 * (lo[1] - 2 * lo[2] * zb), 2 * lo[2]], dY=1e-3))
+    p = O.Problem(geo=geo, h0=np.full(N, hn), Q0=np.full(N, Qb), us=us, ds=ds, theta=theta, dt=dt, dx=dx, nt=nt, tol=1e-6)
+    return p, dict(N=N, b0=b0, S0=S0, Qb=Qb, hn=hn, theta=theta, dt=dt, dx=dx, amp=amp, ds=ds_k, seed=seed)
+
+
 _solved = []
+_solved_table = []
+N_TABLE = 128
+
+
+@pytest.mark.parametrize("seed", range(N_TABLE))
+def test_random_compound_channel_against_the_oracle(seed):
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle as CO
+    p, info = random_table_problem(seed)
+    ref = CO.run(p)
+    if ref["status"] != 0 or not np.all(np.isfinite(ref["depth"])) or np.min(ref["depth"]) <= 1e-3 * info["hn"]:
+        _solved_table.append(False)
+        pytest.skip(f"the oracle does not get through this draw (status {ref['status']}): {info}")
+    _solved_table.append(True)
+    with batch_from_problems([p], mode="table", history=True) as b:
+        b.step(p.nt - 1)
+        assert np.all(b.status() == 0), (b.status(), info)
+        h, Q = b.history_arrays(0, p.nt)
+        its = b.iterations(0, p.nt)[:, 0]
+    d, f = ref["depth"], ref["flow"]
+    eh, eq = rel_err(h[:, 0], d, 1e-3 * info["hn"]), rel_err(Q[:, 0], f, 1e-3 * info["Qb"])
+    assert eh <= TOL and eq <= TOL, (eh, eq, info)
+    assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
+    over = np.any(d > p.geo["h_bf"][None, :]) and np.any(d < p.geo["h_bf"][None, :])
+    info["both_sides_of_bankfull"] = bool(over)
 
 
 @pytest.mark.parametrize("seed", range(N_CASES))
@@ -117,6 +196,7 @@ def test_random_reach_against_the_oracle(seed):
 
 def test_most_draws_are_solvable():
     """the sweep means something only if the reference's algorithm itself gets through most of it"""
-    if len(_solved) < N_CASES:
-        pytest.skip("runs after the sweep")
+    if len(_solved) < N_CASES or len(_solved_table) < N_TABLE:
+        pytest.skip("runs after the sweeps")
     assert sum(_solved) >= 0.8 * N_CASES, f"{sum(_solved)} of {N_CASES}"
+    assert sum(_solved_table) >= 0.7 * N_TABLE, f"{sum(_solved_table)} of {N_TABLE}"
