@@ -598,3 +598,12 @@ def load_fixture(path):
     fx = np.load(path, allow_pickle=False)
     meta = json.loads(str(fx["meta"]))
     return fx, meta
+
+
+def sweep_cases(path):
+    """(index, arrays, meta) of every case of a multi-case fixture (oracle/gen_random_sweep.py: arrays of case i stored
+    as c{i:02d}_<name>, metadata in meta["cases"][i]); each pair goes through problem_from_fixture like a single fixture"""
+    fx, meta = load_fixture(path)
+    for i, m in enumerate(meta["cases"]):
+        pre = f"c{i:02d}_"
+        yield i, {k[len(pre):]: fx[k] for k in fx.files if k.startswith(pre)}, m

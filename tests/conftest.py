@@ -25,7 +25,7 @@ def fixture_paths(host_evaluated=False):
     out = []
     for path in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
         meta = json.loads(str(np.load(path)["meta"]))
-        if "kind" in meta:
+        if "kind" in meta or "cases" in meta:          # data-only fixtures; the multi-case sweep (tests/test_random_sweep.py)
             continue
         if ("host_evaluated" in meta) != host_evaluated:
             continue

@@ -1,0 +1,75 @@
+"""The reference itself, run on 48 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
+
+Channels built through the reference's public API from 2 or 3 input sections - rectangles, trapezoids, compound
+trapezoids - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
+and the initial state), theta 0.55 ... 1, time steps 1 min ... 1 h, spatial steps 50 m ... 1.5 km, 2 ... 257 nodes,
+flow or stage hydrograph upstream, normal depth / power / polynomial rating curve / fixed depth / a storage downstream;
+Newton counts from 3 to 81 per level.
+
+CPU: the numpy and the C oracle against it (1e-8, identical Newton counts).  GPU: the kernel against it, in the table
+mode and - where the channel is a prismatic rectangle - in the rectangular fast path as well."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import preissmann_oracle as O
+
+PATH = os.path.join(GOLDEN, "random_sweep.npz")
+CASES = list(O.sweep_cases(PATH))
+TOL = 1e-8
+
+
+def rel_err(got, want, floor):
+    return float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor)))
+
+
+def label(c):
+    i, _, m = c
+    return f"{i:02d}-{m['family']}-N{m['N']}-{m['ds_kind']}"
+
+
+def compare(res_depth, res_flow, res_iters, fx, m):
+    hn, Qb = m["h_n"], m["Qb"]
+    assert rel_err(res_depth, fx["depth"], 1e-3 * hn) <= TOL
+    assert rel_err(res_flow, fx["flow"], 1e-3 * Qb) <= TOL
+    assert np.array_equal(np.asarray(res_iters), fx["iters"]), (res_iters, fx["iters"])
+
+
+def test_the_sweep_is_what_it_says():
+    fams = {m["family"] for _, _, m in CASES}
+    kinds = {m["ds_kind"] for _, _, m in CASES}
+    ics = {m["ic"] for _, _, m in CASES}
+    assert len(CASES) == 48 and fams == {"rect", "trap", "compound"} and ics == {"steady-state", "GVF_equation", "linear"}
+    assert kinds == {"normal_depth", "power", "polynomial", "fixed_depth", "storage"}
+    assert {m["us_condition"] for _, _, m in CASES} == {"flow_hydrograph", "stage_hydrograph"}
+    assert max(int(fx["iters"].max()) for _, fx, _ in CASES) >= 40          # hard levels are in it
+
+
+@pytest.mark.parametrize("case", CASES, ids=[label(c) for c in CASES])
+def test_oracles_reproduce_the_reference(case):
+    _, fx, m = case
+    p = O.problem_from_fixture(fx, m)
+    r = O.newton_run(p)
+    assert r["status"] == 0
+    compare(r["depth"], r["flow"], r["iters"], fx, m)
+    from oracle import c_oracle as CO
+    rc = CO.run(p)
+    assert rc["status"] == 0
+    compare(rc["depth"], rc["flow"], rc["iters"], fx, m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[label(c) for c in CASES])
+def test_kernel_reproduces_the_reference(case):
+    from fixture_batch import batch_from_problems, is_rect_uniform
+    _, fx, m = case
+    p = O.problem_from_fixture(fx, m)
+    modes = ["table"] + (["rect_uniform"] if is_rect_uniform(p) else [])
+    for mode in modes:
+        with batch_from_problems([p], mode=mode, history=True) as b:
+            b.step(p.nt - 1)
+            assert np.all(b.status() == 0), (mode, b.status())
+            h, Q = b.history_arrays(0, p.nt)
+            compare(h[:, 0], Q[:, 0], b.iterations(0, p.nt)[:, 0], fx, m)
