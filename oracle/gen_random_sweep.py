@@ -24,16 +24,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # (the repository root stays OFF sys.path: its src/ is a regular package and would shadow the reference's namespace package)
 
 
-def build_case(rng):
-    from src.hydromodel.channel import Channel
-    from src.hydromodel.boundary import Boundary
-    from src.hydromodel.preissmann import PreissmannSolver
-    from src.hydromodel.hydrograph import Hydrograph
-    from src.hydromodel.rating_curve import RatingCurve
-    from src.hydromodel.lumped_storage import LumpedStorage
-    from src.hydromodel.cross_section import TrapezoidalSection
-    from gen_golden import akbari_hydrograph
-
+def draw_recipe(rng):
+    """one random channel as plain data (numbers and strings only: it is stored in the fixture's metadata, and
+    tests/test_random_sweep.py rebuilds the same channel through the mirror package from it)"""
     N = int(rng.choice([2, 3, 6, 17, 33, 64, 65, 100, 129, 200, 257]))
     dx = float(int(np.exp(rng.uniform(np.log(50.0), np.log(1500.0)))))
     dt = int(np.exp(rng.uniform(np.log(60.0), np.log(3600.0))))
@@ -52,60 +45,90 @@ def build_case(rng):
     for c in chain:
         z = S0 * (L - c)
         b = b0 * float(rng.uniform(0.85, 1.15)) if n_sections == 3 else b0
-        if family == "rect":
-            sections.append(TrapezoidalSection(z_bed=z, b_main=b, m_main=0.0, n_main=n_main, bed_slope=S0))
-        elif family == "trap":
-            sections.append(TrapezoidalSection(z_bed=z, b_main=b, m_main=float(rng.uniform(0.5, 2.5)), n_main=n_main, bed_slope=S0))
-        else:
-            sections.append(TrapezoidalSection(z_bed=z, b_main=b, m_main=float(rng.uniform(0.5, 2.5)), n_main=n_main, bed_slope=S0,
-                                               z_bank=z + float(rng.uniform(0.8, 3.0)) * (q ** 0.6), b_fp_left=b * float(rng.uniform(0.5, 3)),
-                                               b_fp_right=b * float(rng.uniform(0.5, 3)), m_fp=float(rng.uniform(2, 6)),
-                                               n_left=n_main * float(rng.uniform(1.2, 2)), n_right=n_main * float(rng.uniform(1.2, 2))))
-    h_n = sections[-1].normal_depth(Q_target=Qb)
+        kw = dict(z_bed=z, b_main=b, m_main=0.0, n_main=n_main, bed_slope=S0)
+        if family != "rect":
+            kw["m_main"] = float(rng.uniform(0.5, 2.5))
+        if family == "compound":
+            kw.update(z_bank=z + float(rng.uniform(0.8, 3.0)) * (q ** 0.6), b_fp_left=b * float(rng.uniform(0.5, 3)),
+                      b_fp_right=b * float(rng.uniform(0.5, 3)), m_fp=float(rng.uniform(2, 6)),
+                      n_left=n_main * float(rng.uniform(1.2, 2)), n_right=n_main * float(rng.uniform(1.2, 2)))
+        sections.append(kw)
     amp = float(np.exp(rng.uniform(np.log(0.2), np.log(2.0))))
-    extra = {}
     us_kind = ("flow_hydrograph", "flow_hydrograph", "stage_hydrograph")[rng.integers(0, 3)]
     ic = ("steady-state", "GVF_equation", "linear")[rng.integers(0, 3)]
-    z_us = sections[0].z_bed
-    h_us = sections[0].normal_depth(Q_target=Qb)
-    if us_kind == "flow_hydrograph":
-        hyd = Hydrograph(akbari_hydrograph(Qb, amp * Qb, float(rng.uniform(2, 5)) * dt, float(rng.uniform(6, 12)) * dt))
-        us = Boundary(condition='flow_hydrograph', bed_level=z_us, chainage=0, initial_depth=h_us, hydrograph=hyd)   # (the linear IC reads it)
-    else:
-        t_end = n_steps * dt
-        tab = np.array([[0.0, z_us + h_us], [0.3 * t_end, z_us + h_us * (1 + 0.25 * min(amp, 1.0))], [0.8 * t_end, z_us + h_us * 1.05],
-                        [2.0 * t_end, z_us + h_us]])
-        hyd = Hydrograph(table=tab)
-        us = Boundary(condition='stage_hydrograph', bed_level=z_us, chainage=0, initial_depth=h_us, hydrograph=hyd)
-        extra["us_initial_depth"] = float(h_us)
-        ic = "linear" if ic == "GVF_equation" else ic
+    if us_kind == "stage_hydrograph" and ic == "GVF_equation":
+        ic = "linear"
+    wave = dict(rise=float(rng.uniform(2, 5)) * dt, fall=float(rng.uniform(6, 12)) * dt)
     ds_kind = ("normal_depth", "power", "polynomial", "fixed_depth", "storage")[rng.integers(0, 5)]
     if ds_kind == "storage" and N > 65:
         ds_kind = "normal_depth"
-    if ds_kind == "normal_depth":
+    return dict(N=N, dx=dx, dt=dt, n_steps=n_steps, theta=theta, L=L, S0=S0, family=family, b0=b0, Qb=Qb, chain=chain,
+                sections=sections, amp=amp, us_kind=us_kind, ds_kind=ds_kind, ic=ic, wave=wave,
+                rc_exponent=float(rng.uniform(1.3, 2.0)))
+
+
+def flood_wave(Qb, Qp, rise, fall):
+    """base flow Qb with a sinusoidal rise to Qb + Qp over `rise` seconds and a cosine recession until `fall`"""
+    from math import cos, pi, sin
+
+    def f(t):
+        if t <= rise:
+            return Qb + 0.5 * Qp * (1.0 + sin(pi * t / rise - 0.5 * pi))
+        if t <= fall:
+            return Qb + 0.5 * Qp * (1.0 + cos(pi * (t - rise) / (fall - rise)))
+        return Qb
+    return f
+
+
+def build_from_recipe(r):
+    """the channel and solver of a recipe, through whichever `src.hydromodel` is importable (the reference here, the
+    mirror package in the tests).  Returns (solver, upstream hydrograph, metadata the oracle needs for the boundaries)."""
+    from src.hydromodel.channel import Channel
+    from src.hydromodel.boundary import Boundary
+    from src.hydromodel.preissmann import PreissmannSolver
+    from src.hydromodel.hydrograph import Hydrograph
+    from src.hydromodel.rating_curve import RatingCurve
+    from src.hydromodel.lumped_storage import LumpedStorage
+    from src.hydromodel.cross_section import TrapezoidalSection
+    sections = [TrapezoidalSection(**kw) for kw in r["sections"]]
+    Qb, dt, L = r["Qb"], r["dt"], r["L"]
+    h_n = sections[-1].normal_depth(Q_target=Qb)
+    h_us = sections[0].normal_depth(Q_target=Qb)
+    z_us = sections[0].z_bed
+    extra = {"us_initial_depth": float(h_us), "ds_initial_depth": float(h_n)}
+    if r["us_kind"] == "flow_hydrograph":
+        hyd = Hydrograph(flood_wave(Qb, r["amp"] * Qb, r["wave"]["rise"], r["wave"]["fall"]))
+        us = Boundary(condition='flow_hydrograph', bed_level=z_us, chainage=0, initial_depth=h_us, hydrograph=hyd)   # (the linear IC reads it)
+    else:
+        t_end = r["n_steps"] * dt
+        tab = np.array([[0.0, z_us + h_us], [0.3 * t_end, z_us + h_us * (1 + 0.25 * min(r["amp"], 1.0))],
+                        [0.8 * t_end, z_us + h_us * 1.05], [2.0 * t_end, z_us + h_us]])
+        hyd = Hydrograph(table=tab)
+        us = Boundary(condition='stage_hydrograph', bed_level=z_us, chainage=0, initial_depth=h_us, hydrograph=hyd)
+    kind = r["ds_kind"]
+    if kind == "normal_depth":
         ds = Boundary(condition='normal_depth', bed_level=0.0, chainage=L, initial_depth=h_n)
-    elif ds_kind == "power":
-        be = float(rng.uniform(1.3, 2.0))
-        rc = RatingCurve(); rc.set(type='power', a=Qb / h_n ** be, b=be)
+    elif kind in ("power", "polynomial"):
+        rc = RatingCurve()
+        if kind == "power":
+            be = r["rc_exponent"]
+            rc.set(type='power', a=Qb / h_n ** be, b=be)
+            extra.update(ds_rc_type="power", ds_rc_a=float(rc.a), ds_rc_b=float(rc.b), ds_rc_shift=0.0)
+        else:
+            rc.set(type='polynomial', a=0.2 * Qb / h_n ** 2, b=0.8 * Qb / h_n, c=0.0)
+            extra.update(ds_rc_type="polynomial", ds_rc_a=float(rc.a), ds_rc_b=float(rc.b), ds_rc_c=0.0, ds_rc_shift=0.0)
         ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_n, rating_curve=rc)
-        extra.update(ds_rc_type="power", ds_rc_a=float(rc.a), ds_rc_b=float(rc.b), ds_rc_shift=0.0)
-    elif ds_kind == "polynomial":
-        rc = RatingCurve(); rc.set(type='polynomial', a=0.2 * Qb / h_n ** 2, b=0.8 * Qb / h_n, c=0.0)
-        ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_n, rating_curve=rc)
-        extra.update(ds_rc_type="polynomial", ds_rc_a=float(rc.a), ds_rc_b=float(rc.b), ds_rc_c=0.0, ds_rc_shift=0.0)
-    elif ds_kind == "fixed_depth":
-        ds = Boundary(condition='fixed_depth', bed_level=0.0, chainage=L, initial_depth=h_n)
     else:
         ds = Boundary(condition='fixed_depth', bed_level=0.0, chainage=L, initial_depth=h_n)
-        area = float(max(30.0 * b0 * L / 40.0, 5e3))
-        ds.set_lumped_storage(LumpedStorage(surface_area=area, min_stage=0.5 * h_n, solution_boundaries=(0.0, 60.0 * h_n)))
-        extra.update(storage_area=area, storage_min_stage=0.5 * h_n, storage_bounds=[0.0, 60.0 * h_n])
-    extra["ds_initial_depth"] = float(h_n)
-    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method=ic)
-    ch.set_cross_sections(chain, sections)
-    sol = PreissmannSolver(channel=ch, theta=theta, time_step=dt, spatial_step=dx, simulation_time=n_steps * dt)
-    info = dict(family=family, n_sections=n_sections, us_kind=us_kind, ds_kind=ds_kind, ic=ic, Qb=Qb, h_n=float(h_n), amp=amp)
-    return sol, hyd, extra, info
+        if kind == "storage":
+            area = float(max(30.0 * r["b0"] * L / 40.0, 5e3))
+            ds.set_lumped_storage(LumpedStorage(surface_area=area, min_stage=0.5 * h_n, solution_boundaries=(0.0, 60.0 * h_n)))
+            extra.update(storage_area=area, storage_min_stage=0.5 * h_n, storage_bounds=[0.0, 60.0 * h_n])
+    ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method=r["ic"])
+    ch.set_cross_sections(r["chain"], sections)
+    sol = PreissmannSolver(channel=ch, theta=r["theta"], time_step=dt, spatial_step=r["dx"], simulation_time=r["n_steps"] * dt)
+    extra["h_n"] = float(h_n)
+    return sol, hyd, extra
 
 
 def main():
@@ -123,8 +146,9 @@ def main():
     arrays, metas, tried, t0 = {}, [], 0, time.time()
     while len(metas) < a.cases and tried < 6 * a.cases:
         tried += 1
+        recipe = draw_recipe(rng)
         try:
-            sol, hyd, extra, info = build_case(rng)
+            sol, hyd, extra = build_from_recipe(recipe)
             out, wall = run_and_capture(sol, 1e-6, slim=True)
         except (ValueError, RuntimeError, ZeroDivisionError, FloatingPointError) as e:      # the reference gives up on this draw
             print(f"  draw {tried}: reference raised {type(e).__name__}: {str(e)[:70]}")
@@ -132,17 +156,17 @@ def main():
         if not (np.all(np.isfinite(out["depth"])) and np.min(out["depth"]) > 0):
             continue
         i = len(metas)
-        side = "us"
-        out[f"{side}_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+        out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
         for k in ("R0", "norm_level", "norm_value", "final_unknowns"):
             out.pop(k, None)
         for k, v in out.items():
             arrays[f"c{i:02d}_{k}"] = v
         m = base_meta(sol, 1e-6, wall, **extra)
-        m.update(info)
+        m.update(family=recipe["family"], n_sections=len(recipe["chain"]), us_kind=recipe["us_kind"], ds_kind=recipe["ds_kind"],
+                 ic=recipe["ic"], Qb=recipe["Qb"], amp=recipe["amp"], recipe=recipe)
         metas.append(m)
-        print(f"  case {i:02d}: N={m['N']:4d} nt={m['nt']} {info['family']:8s} x{info['n_sections']} {info['us_kind'][:5]} -> {info['ds_kind']:12s} "
-              f"ic={info['ic']:12s} its={out['iters'][1:].tolist()}")
+        print(f"  case {i:02d}: N={m['N']:4d} nt={m['nt']} {m['family']:8s} x{m['n_sections']} {m['us_kind'][:5]} -> {m['ds_kind']:12s} "
+              f"ic={m['ic']:12s} its={out['iters'][1:].tolist()}")
     meta = dict(generator="oracle/gen_random_sweep.py", reference="cve-mohd/flow-sim snapshot 2026-02-13, run in the build container",
                 seed=a.seed, draws=tried, cases=metas)
     path = os.path.join(ROOT, "tests", "golden", "random_sweep.npz")

@@ -6,8 +6,11 @@ and the initial state), theta 0.55 ... 1, time steps 1 min ... 1 h, spatial step
 flow or stage hydrograph upstream, normal depth / power / polynomial rating curve / fixed depth / a storage downstream;
 Newton counts from 3 to 81 per level.
 
-CPU: the numpy and the C oracle against it (1e-8, identical Newton counts).  GPU: the kernel against it, in the table
-mode and - where the channel is a prismatic rectangle - in the rectangular fast path as well."""
+CPU: the numpy and the C oracle against it (1e-8, identical Newton counts); the mirror package, given the same recipe
+(stored as plain data in the fixture's metadata), builds the same grid, node geometry, initial conditions and boundary
+targets.  GPU: the kernel against it, in the table mode and - where the channel is a prismatic rectangle - in the
+rectangular fast path as well; and the whole path a case script takes: Channel / Boundary / PreissmannSolver(...).run()
+of the mirror package against the reference's depth / flow histories."""
 import os
 
 import numpy as np
@@ -15,6 +18,7 @@ import pytest
 
 from conftest import GOLDEN
 from oracle import preissmann_oracle as O
+from oracle.gen_random_sweep import build_from_recipe
 
 PATH = os.path.join(GOLDEN, "random_sweep.npz")
 CASES = list(O.sweep_cases(PATH))
@@ -73,3 +77,36 @@ def test_kernel_reproduces_the_reference(case):
             assert np.all(b.status() == 0), (mode, b.status())
             h, Q = b.history_arrays(0, p.nt)
             compare(h[:, 0], Q[:, 0], b.iterations(0, p.nt)[:, 0], fx, m)
+
+
+GEO = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf", "b_fp_l", "b_fp_r", "m_fp", "curvature")
+
+
+@pytest.mark.parametrize("case", CASES, ids=[label(c) for c in CASES])
+def test_mirror_sets_the_channel_up_as_the_reference_does(case):
+    """grid fitting (solver.py:56-58), section interpolation (cross_section.py:857-930), the three initial-condition
+    methods (channel.py:296-390), hydrograph sampling - through the mirror's public API from the stored recipe"""
+    _, fx, m = case
+    solver, hyd, extra = build_from_recipe(m["recipe"])
+    assert type(solver).__module__.startswith("flowsim_amd")          # the mirror, not the reference
+    assert solver.number_of_nodes == m["N"] and solver.number_of_time_levels == m["nt"]
+    assert abs(solver.spatial_step - m["dx"]) <= 1e-12 * m["dx"]
+    ch = solver.channel
+    for k in GEO:
+        np.testing.assert_allclose(ch.node_geometry[k], fx["geo_" + k], rtol=1e-13, atol=1e-15, err_msg=k)
+    np.testing.assert_allclose(ch.ch_at_node, fx["geo_chainage"], rtol=1e-14)
+    np.testing.assert_allclose(ch.initial_conditions, fx["initial_conditions"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose([hyd.get_at(k * solver.time_step) for k in range(m["nt"])], fx["us_target"], rtol=1e-14)
+    for key in ("us_initial_depth", "ds_initial_depth", "ds_rc_a", "storage_area"):
+        if key in m:
+            assert abs(extra[key] - m[key]) <= 1e-12 * abs(m[key])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=[label(c) for c in CASES])
+def test_case_script_path_reproduces_the_reference(case):
+    """what a case script does - build the objects, run(), read solver.depth / solver.flow - on the mirror package"""
+    _, fx, m = case
+    solver, _, _ = build_from_recipe(m["recipe"])
+    solver.run(tolerance=m["tolerance"], verbose=0, max_iter=m["max_iter"])
+    compare(solver.depth, solver.flow, solver.iterations, fx, m)
