@@ -8,7 +8,7 @@ generators pin the path at a handful of parameter points; this pins it across th
 and GVF code produce the node geometry and the initial state), theta, time and space steps over two decades, five
 downstream boundary kinds incl. a storage, flow or stage hydrograph upstream.
 
-    python oracle/gen_random_sweep.py [--cases 48]
+    python oracle/gen_random_sweep.py [--cases 48] [--polyline 12]
 
 Arrays of case i are stored as c{i:02d}_<name>, the per-case metadata as the list meta["cases"].
 """
@@ -67,6 +67,61 @@ def draw_recipe(rng):
                 rc_exponent=float(rng.uniform(1.3, 2.0)))
 
 
+def draw_polyline_recipe(rng):
+    """a channel of polyline sections (IrregularSection, cross_section.py:207-543): a valley of 7 ... 12 stations, in half
+    of the draws with a levee that splits the section at low stages, composite roughness over three strips; the two input
+    sections differ (union of stations at the interpolated nodes), one of them may be a trapezoid (mixed interpolation)"""
+    N = int(rng.choice([3, 9, 17, 33, 65]))
+    dx = float(int(np.exp(rng.uniform(np.log(100.0), np.log(800.0)))))
+    dt = int(np.exp(rng.uniform(np.log(120.0), np.log(1800.0))))
+    n_steps = int(rng.integers(2, 5))
+    theta = float(rng.uniform(0.55, 1.0))
+    L = (N - 1) * dx
+    S0 = float(np.exp(rng.uniform(np.log(1.5e-4), np.log(1.5e-3))))
+    W = float(np.exp(rng.uniform(np.log(30.0), np.log(200.0))))
+    n_main = float(rng.uniform(0.025, 0.04))
+
+    def valley(scale):
+        k = int(rng.integers(7, 13))
+        x = np.sort(np.concatenate(([0.0, 1.0], rng.uniform(0.05, 0.95, k - 2))))
+        x[1:-1] += np.linspace(-0.01, 0.01, k - 2)                       # no tied stations
+        x = np.sort(x)
+        c = float(rng.uniform(0.35, 0.65))
+        z = 7.0 * np.abs(x - c) ** float(rng.uniform(1.0, 2.0)) / max(c, 1 - c) ** 1.5
+        z += rng.uniform(0.0, 0.25, k)
+        if rng.integers(0, 2):                                             # a levee with low ground behind it
+            j = int(np.clip(np.searchsorted(x, c + 0.2), 2, k - 3))
+            z[j] += float(rng.uniform(1.0, 2.0))
+            z[j + 1] = max(z[j] - float(rng.uniform(0.8, 1.6)), 0.3)
+        z[0] = z[-1] = 9.0
+        z -= z.min()
+        return (x * W * scale).tolist(), z.tolist()
+    sections = []
+    for pos, c in enumerate([0.0, L]):
+        if pos == 0 and rng.integers(0, 4) == 0:
+            sections.append(dict(z_bed=S0 * L, b_main=0.4 * W, m_main=float(rng.uniform(1.0, 2.5)), n_main=n_main, bed_slope=S0))
+            continue
+        x, z = valley(1.0 if pos == 0 else float(rng.uniform(0.9, 1.2)))
+        lim = sorted(rng.uniform(0.15, 0.85, 2) * x[-1])
+        sections.append(dict(x=x, z=(np.array(z) + S0 * (L - c)).tolist(), n=n_main * (1.0 if pos == 0 else float(rng.uniform(0.9, 1.15))),
+                             bed_slope=S0, roughness=[n_main * 1.6, n_main, n_main * 1.8, float(lim[0]), float(lim[1])]))
+    Qb = float(np.exp(rng.uniform(np.log(0.15), np.log(1.5)))) * W
+    amp = float(np.exp(rng.uniform(np.log(0.5), np.log(4.0))))
+    ds_kind = ("normal_depth", "power", "fixed_depth")[rng.integers(0, 3)]
+    return dict(N=N, dx=dx, dt=dt, n_steps=n_steps, theta=theta, L=L, S0=S0, family="polyline", b0=W, Qb=Qb, chain=[0.0, L],
+                sections=sections, amp=amp, us_kind="flow_hydrograph", ds_kind=ds_kind, ic=("steady-state", "linear")[rng.integers(0, 2)],
+                wave=dict(rise=float(rng.uniform(2, 4)) * dt, fall=float(rng.uniform(5, 9)) * dt), rc_exponent=float(rng.uniform(1.4, 2.0)))
+
+
+def make_section(kw):
+    from src.hydromodel.cross_section import IrregularSection, TrapezoidalSection
+    if "x" not in kw:
+        return TrapezoidalSection(**kw)
+    s = IrregularSection(x=np.array(kw["x"]), z=np.array(kw["z"]), n=kw["n"], bed_slope=kw["bed_slope"])
+    s.set_roughness_para(tuple(kw["roughness"]))
+    return s
+
+
 def flood_wave(Qb, Qp, rise, fall):
     """base flow Qb with a sinusoidal rise to Qb + Qp over `rise` seconds and a cosine recession until `fall`"""
     from math import cos, pi, sin
@@ -89,12 +144,11 @@ def build_from_recipe(r):
     from src.hydromodel.hydrograph import Hydrograph
     from src.hydromodel.rating_curve import RatingCurve
     from src.hydromodel.lumped_storage import LumpedStorage
-    from src.hydromodel.cross_section import TrapezoidalSection
-    sections = [TrapezoidalSection(**kw) for kw in r["sections"]]
+    sections = [make_section(kw) for kw in r["sections"]]
     Qb, dt, L = r["Qb"], r["dt"], r["L"]
     h_n = sections[-1].normal_depth(Q_target=Qb)
     h_us = sections[0].normal_depth(Q_target=Qb)
-    z_us = sections[0].z_bed
+    z_us = sections[0].z_min
     extra = {"us_initial_depth": float(h_us), "ds_initial_depth": float(h_n)}
     if r["us_kind"] == "flow_hydrograph":
         hyd = Hydrograph(flood_wave(Qb, r["amp"] * Qb, r["wave"]["rise"], r["wave"]["fall"]))
@@ -134,6 +188,7 @@ def build_from_recipe(r):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=48)
+    ap.add_argument("--polyline", type=int, default=12)
     ap.add_argument("--seed", type=int, default=20260301)
     a = ap.parse_args()
     sys.dont_write_bytecode = True
@@ -143,10 +198,12 @@ def main():
     from gen_golden import base_meta, run_and_capture, sample_targets
 
     rng = np.random.default_rng(a.seed)
+    rng_poly = np.random.default_rng(a.seed + 1)          # a stream of its own: the trapezoid-family cases stay what they were
     arrays, metas, tried, t0 = {}, [], 0, time.time()
-    while len(metas) < a.cases and tried < 6 * a.cases:
+    total = a.cases + a.polyline
+    while len(metas) < total and tried < 6 * total:
         tried += 1
-        recipe = draw_recipe(rng)
+        recipe = draw_recipe(rng) if len(metas) < a.cases else draw_polyline_recipe(rng_poly)
         try:
             sol, hyd, extra = build_from_recipe(recipe)
             out, wall = run_and_capture(sol, 1e-6, slim=True)

@@ -1,7 +1,8 @@
-"""The reference itself, run on 48 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
+"""The reference itself, run on 60 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
 
 Channels built through the reference's public API from 2 or 3 input sections - rectangles, trapezoids, compound
-trapezoids - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
+trapezoids, and 12 channels of polyline sections (valleys of 7 ... 12 stations, half of them split by a levee at low stages,
+composite roughness, one mixed trapezoid -> polyline interpolation) - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
 and the initial state), theta 0.55 ... 1, time steps 1 min ... 1 h, spatial steps 50 m ... 1.5 km, 2 ... 257 nodes,
 flow or stage hydrograph upstream, normal depth / power / polynomial rating curve / fixed depth / a storage downstream;
 Newton counts from 3 to 81 per level.
@@ -45,7 +46,8 @@ def test_the_sweep_is_what_it_says():
     fams = {m["family"] for _, _, m in CASES}
     kinds = {m["ds_kind"] for _, _, m in CASES}
     ics = {m["ic"] for _, _, m in CASES}
-    assert len(CASES) == 48 and fams == {"rect", "trap", "compound"} and ics == {"steady-state", "GVF_equation", "linear"}
+    assert len(CASES) == 60 and fams == {"rect", "trap", "compound", "polyline"} and ics == {"steady-state", "GVF_equation", "linear"}
+    assert sum(m["family"] == "polyline" for _, _, m in CASES) == 12
     assert kinds == {"normal_depth", "power", "polynomial", "fixed_depth", "storage"}
     assert {m["us_condition"] for _, _, m in CASES} == {"flow_hydrograph", "stage_hydrograph"}
     assert max(int(fx["iters"].max()) for _, fx, _ in CASES) >= 40          # hard levels are in it
@@ -58,10 +60,11 @@ def test_oracles_reproduce_the_reference(case):
     r = O.newton_run(p)
     assert r["status"] == 0
     compare(r["depth"], r["flow"], r["iters"], fx, m)
-    from oracle import c_oracle as CO
-    rc = CO.run(p)
-    assert rc["status"] == 0
-    compare(rc["depth"], rc["flow"], rc["iters"], fx, m)
+    if m["family"] != "polyline":                  # the C restatement covers the trapezoid family
+        from oracle import c_oracle as CO
+        rc = CO.run(p)
+        assert rc["status"] == 0
+        compare(rc["depth"], rc["flow"], rc["iters"], fx, m)
 
 
 @pytest.mark.gpu
@@ -70,7 +73,7 @@ def test_kernel_reproduces_the_reference(case):
     from fixture_batch import batch_from_problems, is_rect_uniform
     _, fx, m = case
     p = O.problem_from_fixture(fx, m)
-    modes = ["table"] + (["rect_uniform"] if is_rect_uniform(p) else [])
+    modes = ["irregular"] if m["family"] == "polyline" else ["table"] + (["rect_uniform"] if is_rect_uniform(p) else [])
     for mode in modes:
         with batch_from_problems([p], mode=mode, history=True) as b:
             b.step(p.nt - 1)
@@ -94,6 +97,13 @@ def test_mirror_sets_the_channel_up_as_the_reference_does(case):
     ch = solver.channel
     for k in GEO:
         np.testing.assert_allclose(ch.node_geometry[k], fx["geo_" + k], rtol=1e-13, atol=1e-15, err_msg=k)
+    if "geo_irr_npts" in fx:                             # polyline nodes: union of the stations, blended elevations
+        cnt = fx["geo_irr_npts"]
+        assert np.array_equal(ch.node_geometry["irr_npts"], cnt)
+        for i, c in enumerate(cnt):
+            np.testing.assert_allclose(ch.node_geometry["irr_x"][i, :c], fx["geo_irr_x"][i, :c], rtol=1e-13, atol=1e-13)
+            np.testing.assert_allclose(ch.node_geometry["irr_z"][i, :c], fx["geo_irr_z"][i, :c], rtol=1e-13, atol=1e-13)
+        np.testing.assert_allclose(ch.node_geometry["irr_limits"], fx["geo_irr_limits"], rtol=1e-13)
     np.testing.assert_allclose(ch.ch_at_node, fx["geo_chainage"], rtol=1e-14)
     np.testing.assert_allclose(ch.initial_conditions, fx["initial_conditions"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose([hyd.get_at(k * solver.time_step) for k in range(m["nt"])], fx["us_target"], rtol=1e-14)
