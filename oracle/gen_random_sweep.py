@@ -8,7 +8,7 @@ generators pin the path at a handful of parameter points; this pins it across th
 and GVF code produce the node geometry and the initial state), theta, time and space steps over two decades, five
 downstream boundary kinds incl. a storage, flow or stage hydrograph upstream.
 
-    python oracle/gen_random_sweep.py [--cases 48] [--polyline 12]
+    python oracle/gen_random_sweep.py [--cases 48] [--polyline 12] [--storage 12]
 
 Arrays of case i are stored as c{i:02d}_<name>, the per-case metadata as the list meta["cases"].
 """
@@ -113,6 +113,24 @@ def draw_polyline_recipe(rng):
                 wave=dict(rise=float(rng.uniform(2, 4)) * dt, fall=float(rng.uniform(5, 9)) * dt), rc_exponent=float(rng.uniform(1.4, 2.0)))
 
 
+def draw_storage_recipe(rng):
+    """a short trapezoid / rectangle reach that ends in a general LumpedStorage (lumped_storage.py:24-179): area curve with
+    scale and shift, optionally an outflow rating curve (power / polynomial) and entrance losses - the mass-balance root is
+    a brentq on the reference side, a Brent iteration inside the kernel on ours"""
+    r = draw_recipe(rng)
+    while r["family"] == "compound" or r["N"] > 65 or r["N"] < 3:
+        r = draw_recipe(rng)
+    r["us_kind"], r["ic"] = "flow_hydrograph", ("steady-state", "GVF_equation")[rng.integers(0, 2)]
+    r["ds_kind"] = "storage_curve"
+    width = r["b0"]
+    a0 = float(np.exp(rng.uniform(np.log(20.0), np.log(400.0)))) * width * r["dx"] / 50.0
+    r["storage"] = dict(a0=a0, a1=a0 * float(rng.uniform(0.02, 0.3)), a2=a0 * float(rng.uniform(0.0, 0.02)), alpha=float(rng.uniform(0.8, 1.3)),
+                        beta=float(rng.uniform(-0.3, 0.3)), rc_type=(None, "power", "polynomial")[rng.integers(0, 3)],
+                        rc_exponent=float(rng.uniform(1.3, 1.9)), losses=bool(rng.integers(0, 2)),
+                        reservoir_length=float(rng.uniform(100.0, 2000.0)), K_q=float(rng.uniform(0.0, 0.6)))
+    return r
+
+
 def make_section(kw):
     from src.hydromodel.cross_section import IrregularSection, TrapezoidalSection
     if "x" not in kw:
@@ -174,6 +192,26 @@ def build_from_recipe(r):
         ds = Boundary(condition='rating_curve', bed_level=0.0, chainage=L, initial_depth=h_n, rating_curve=rc)
     else:
         ds = Boundary(condition='fixed_depth', bed_level=0.0, chainage=L, initial_depth=h_n)
+        if kind == "storage_curve":
+            st = r["storage"]
+            stages = np.arange(0.0, 40.0 * h_n + 1e-9, 0.25 * h_n)
+            curve = np.column_stack([stages, st["a0"] + st["a1"] * stages + st["a2"] * stages ** 2])
+            rc = None
+            extra.update(storage_curve=curve.tolist(), storage_alpha=st["alpha"], storage_beta=st["beta"], storage_min_stage=0.5 * h_n,
+                         storage_rc_type=st["rc_type"])
+            if st["rc_type"] == "power":
+                rc = RatingCurve(); rc.set(type='power', a=0.6 * Qb / h_n ** st["rc_exponent"], b=st["rc_exponent"])
+                extra.update(storage_rc=dict(a=float(rc.a), b=float(rc.b), shift=0.0))
+            elif st["rc_type"] == "polynomial":
+                rc = RatingCurve(); rc.set(type='polynomial', a=0.1 * Qb / h_n ** 2, b=0.5 * Qb / h_n, c=0.0)
+                extra.update(storage_rc=dict(a=float(rc.a), b=float(rc.b), c=0.0, shift=0.0))
+            ss = LumpedStorage(surface_area=None, min_stage=0.5 * h_n, solution_boundaries=(0, 40.0 * h_n), rating_curve=rc)
+            ss.set_area_curve(curve, alpha=st["alpha"], beta=st["beta"])
+            if st["losses"]:
+                ss.capture_losses, ss.reservoir_length, ss.K_q = True, st["reservoir_length"], st["K_q"]
+                extra.update(storage_losses=dict(reservoir_length=st["reservoir_length"], K_q=st["K_q"]))
+            extra["storage_bounds"] = [float(ss.Y_min), float(ss.Y_max)]
+            ds.set_lumped_storage(ss)
         if kind == "storage":
             area = float(max(30.0 * r["b0"] * L / 40.0, 5e3))
             ds.set_lumped_storage(LumpedStorage(surface_area=area, min_stage=0.5 * h_n, solution_boundaries=(0.0, 60.0 * h_n)))
@@ -189,6 +227,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=48)
     ap.add_argument("--polyline", type=int, default=12)
+    ap.add_argument("--storage", type=int, default=12)
     ap.add_argument("--seed", type=int, default=20260301)
     a = ap.parse_args()
     sys.dont_write_bytecode = True
@@ -200,10 +239,12 @@ def main():
     rng = np.random.default_rng(a.seed)
     rng_poly = np.random.default_rng(a.seed + 1)          # a stream of its own: the trapezoid-family cases stay what they were
     arrays, metas, tried, t0 = {}, [], 0, time.time()
-    total = a.cases + a.polyline
+    rng_store = np.random.default_rng(a.seed + 2)
+    total = a.cases + a.polyline + a.storage
     while len(metas) < total and tried < 6 * total:
         tried += 1
-        recipe = draw_recipe(rng) if len(metas) < a.cases else draw_polyline_recipe(rng_poly)
+        recipe = (draw_recipe(rng) if len(metas) < a.cases else draw_polyline_recipe(rng_poly) if len(metas) < a.cases + a.polyline
+                  else draw_storage_recipe(rng_store))
         try:
             sol, hyd, extra = build_from_recipe(recipe)
             out, wall = run_and_capture(sol, 1e-6, slim=True)

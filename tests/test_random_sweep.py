@@ -1,8 +1,9 @@
-"""The reference itself, run on 60 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
+"""The reference itself, run on 72 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
 
 Channels built through the reference's public API from 2 or 3 input sections - rectangles, trapezoids, compound
 trapezoids, and 12 channels of polyline sections (valleys of 7 ... 12 stations, half of them split by a levee at low stages,
-composite roughness, one mixed trapezoid -> polyline interpolation) - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
+composite roughness, one mixed trapezoid -> polyline interpolation), and 12 reaches that end in a general LumpedStorage
+(area curve, optional outflow rating curve, optional entrance losses: brentq there, Brent in the kernel here) - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
 and the initial state), theta 0.55 ... 1, time steps 1 min ... 1 h, spatial steps 50 m ... 1.5 km, 2 ... 257 nodes,
 flow or stage hydrograph upstream, normal depth / power / polynomial rating curve / fixed depth / a storage downstream;
 Newton counts from 3 to 81 per level.
@@ -46,9 +47,9 @@ def test_the_sweep_is_what_it_says():
     fams = {m["family"] for _, _, m in CASES}
     kinds = {m["ds_kind"] for _, _, m in CASES}
     ics = {m["ic"] for _, _, m in CASES}
-    assert len(CASES) == 60 and fams == {"rect", "trap", "compound", "polyline"} and ics == {"steady-state", "GVF_equation", "linear"}
-    assert sum(m["family"] == "polyline" for _, _, m in CASES) == 12
-    assert kinds == {"normal_depth", "power", "polynomial", "fixed_depth", "storage"}
+    assert len(CASES) == 72 and fams == {"rect", "trap", "compound", "polyline"} and ics == {"steady-state", "GVF_equation", "linear"}
+    assert sum(m["family"] == "polyline" for _, _, m in CASES) == 12 and sum(m["ds_kind"] == "storage_curve" for _, _, m in CASES) == 12
+    assert kinds == {"normal_depth", "power", "polynomial", "fixed_depth", "storage", "storage_curve"}
     assert {m["us_condition"] for _, _, m in CASES} == {"flow_hydrograph", "stage_hydrograph"}
     assert max(int(fx["iters"].max()) for _, fx, _ in CASES) >= 40          # hard levels are in it
 
@@ -60,7 +61,7 @@ def test_oracles_reproduce_the_reference(case):
     r = O.newton_run(p)
     assert r["status"] == 0
     compare(r["depth"], r["flow"], r["iters"], fx, m)
-    if m["family"] != "polyline":                  # the C restatement covers the trapezoid family
+    if m["family"] != "polyline" and m["ds_kind"] != "storage_curve":        # the C restatement: trapezoid family, closed-form boundaries
         from oracle import c_oracle as CO
         rc = CO.run(p)
         assert rc["status"] == 0
@@ -73,7 +74,9 @@ def test_kernel_reproduces_the_reference(case):
     from fixture_batch import batch_from_problems, is_rect_uniform
     _, fx, m = case
     p = O.problem_from_fixture(fx, m)
-    modes = ["irregular"] if m["family"] == "polyline" else ["table"] + (["rect_uniform"] if is_rect_uniform(p) else [])
+    # (the general storage row is compiled into the table / polyline kernels only: fs_batch_step says so otherwise)
+    fast = is_rect_uniform(p) and m["ds_kind"] != "storage_curve"
+    modes = ["irregular"] if m["family"] == "polyline" else ["table"] + (["rect_uniform"] if fast else [])
     for mode in modes:
         with batch_from_problems([p], mode=mode, history=True) as b:
             b.step(p.nt - 1)
