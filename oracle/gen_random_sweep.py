@@ -8,7 +8,7 @@ generators pin the path at a handful of parameter points; this pins it across th
 and GVF code produce the node geometry and the initial state), theta, time and space steps over two decades, five
 downstream boundary kinds incl. a storage, flow or stage hydrograph upstream.
 
-    python oracle/gen_random_sweep.py [--cases 48] [--polyline 12] [--storage 12]
+    python oracle/gen_random_sweep.py [--cases 48] [--polyline 12] [--storage 12] [--bends 8]
 
 Arrays of case i are stored as c{i:02d}_<name>, the per-case metadata as the list meta["cases"].
 """
@@ -131,6 +131,23 @@ def draw_storage_recipe(rng):
     return r
 
 
+def draw_bend_recipe(rng):
+    """three input sections along a meandering centre line (Channel.set_coords): the reference derives a curvature for the
+    middle section from the turning of the line (channel.py:243-277), interpolates it to the nodes, and the energy slope
+    gains the transverse-circulation term (hydraulics.py:94-153)"""
+    r = draw_recipe(rng)
+    while len(r["chain"]) != 3 or r["N"] < 9 or r["L"] > 12000.0:        # (the three-point curvature is at most 4 / L)
+        r = draw_recipe(rng)
+    L = r["L"]
+    k = int(rng.integers(4, 8))
+    s = np.sort(np.concatenate(([0.0, L], rng.uniform(0.05, 0.95, k - 2) * L)))
+    heading = np.cumsum(rng.uniform(-1.0, 1.0, k))
+    step = np.diff(s, prepend=0.0)
+    xy = np.column_stack([np.cumsum(step * np.cos(heading)), np.cumsum(step * np.sin(heading))])
+    r["coords"] = dict(xy=xy.tolist(), chainages=s.tolist())
+    return r
+
+
 def make_section(kw):
     from src.hydromodel.cross_section import IrregularSection, TrapezoidalSection
     if "x" not in kw:
@@ -217,6 +234,8 @@ def build_from_recipe(r):
             ds.set_lumped_storage(LumpedStorage(surface_area=area, min_stage=0.5 * h_n, solution_boundaries=(0.0, 60.0 * h_n)))
             extra.update(storage_area=area, storage_min_stage=0.5 * h_n, storage_bounds=[0.0, 60.0 * h_n])
     ch = Channel(initial_flow=Qb, upstream_boundary=us, downstream_boundary=ds, interpolation_method=r["ic"])
+    if "coords" in r:
+        ch.set_coords(coords=np.array(r["coords"]["xy"]), chainages=np.array(r["coords"]["chainages"]))
     ch.set_cross_sections(r["chain"], sections)
     sol = PreissmannSolver(channel=ch, theta=r["theta"], time_step=dt, spatial_step=r["dx"], simulation_time=r["n_steps"] * dt)
     extra["h_n"] = float(h_n)
@@ -228,6 +247,7 @@ def main():
     ap.add_argument("--cases", type=int, default=48)
     ap.add_argument("--polyline", type=int, default=12)
     ap.add_argument("--storage", type=int, default=12)
+    ap.add_argument("--bends", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20260301)
     a = ap.parse_args()
     sys.dont_write_bytecode = True
@@ -240,11 +260,13 @@ def main():
     rng_poly = np.random.default_rng(a.seed + 1)          # a stream of its own: the trapezoid-family cases stay what they were
     arrays, metas, tried, t0 = {}, [], 0, time.time()
     rng_store = np.random.default_rng(a.seed + 2)
-    total = a.cases + a.polyline + a.storage
+    rng_bend = np.random.default_rng(a.seed + 3)
+    total = a.cases + a.polyline + a.storage + a.bends
     while len(metas) < total and tried < 6 * total:
         tried += 1
-        recipe = (draw_recipe(rng) if len(metas) < a.cases else draw_polyline_recipe(rng_poly) if len(metas) < a.cases + a.polyline
-                  else draw_storage_recipe(rng_store))
+        n = len(metas)
+        recipe = (draw_recipe(rng) if n < a.cases else draw_polyline_recipe(rng_poly) if n < a.cases + a.polyline
+                  else draw_storage_recipe(rng_store) if n < a.cases + a.polyline + a.storage else draw_bend_recipe(rng_bend))
         try:
             sol, hyd, extra = build_from_recipe(recipe)
             out, wall = run_and_capture(sol, 1e-6, slim=True)
@@ -261,7 +283,7 @@ def main():
             arrays[f"c{i:02d}_{k}"] = v
         m = base_meta(sol, 1e-6, wall, **extra)
         m.update(family=recipe["family"], n_sections=len(recipe["chain"]), us_kind=recipe["us_kind"], ds_kind=recipe["ds_kind"],
-                 ic=recipe["ic"], Qb=recipe["Qb"], amp=recipe["amp"], recipe=recipe)
+                 ic=recipe["ic"], Qb=recipe["Qb"], amp=recipe["amp"], bends="coords" in recipe, recipe=recipe)
         metas.append(m)
         print(f"  case {i:02d}: N={m['N']:4d} nt={m['nt']} {m['family']:8s} x{m['n_sections']} {m['us_kind'][:5]} -> {m['ds_kind']:12s} "
               f"ic={m['ic']:12s} its={out['iters'][1:].tolist()}")

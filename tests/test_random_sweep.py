@@ -1,9 +1,10 @@
-"""The reference itself, run on 72 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
+"""The reference itself, run on 80 seeded random channels (oracle/gen_random_sweep.py -> tests/golden/random_sweep.npz).
 
 Channels built through the reference's public API from 2 or 3 input sections - rectangles, trapezoids, compound
 trapezoids, and 12 channels of polyline sections (valleys of 7 ... 12 stations, half of them split by a levee at low stages,
 composite roughness, one mixed trapezoid -> polyline interpolation), and 12 reaches that end in a general LumpedStorage
-(area curve, optional outflow rating curve, optional entrance losses: brentq there, Brent in the kernel here) - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
+(area curve, optional outflow rating curve, optional entrance losses: brentq there, Brent in the kernel here), and 8
+three-section channels along a meandering centre line (curvature from the coordinates, transverse-circulation slope) - with all three initial-condition methods (so its own interpolation and GVF code produced the node geometry
 and the initial state), theta 0.55 ... 1, time steps 1 min ... 1 h, spatial steps 50 m ... 1.5 km, 2 ... 257 nodes,
 flow or stage hydrograph upstream, normal depth / power / polynomial rating curve / fixed depth / a storage downstream;
 Newton counts from 3 to 81 per level.
@@ -47,10 +48,12 @@ def test_the_sweep_is_what_it_says():
     fams = {m["family"] for _, _, m in CASES}
     kinds = {m["ds_kind"] for _, _, m in CASES}
     ics = {m["ic"] for _, _, m in CASES}
-    assert len(CASES) == 72 and fams == {"rect", "trap", "compound", "polyline"} and ics == {"steady-state", "GVF_equation", "linear"}
+    assert len(CASES) == 80 and fams == {"rect", "trap", "compound", "polyline"} and ics == {"steady-state", "GVF_equation", "linear"}
     assert sum(m["family"] == "polyline" for _, _, m in CASES) == 12 and sum(m["ds_kind"] == "storage_curve" for _, _, m in CASES) == 12
     assert kinds == {"normal_depth", "power", "polynomial", "fixed_depth", "storage", "storage_curve"}
     assert {m["us_condition"] for _, _, m in CASES} == {"flow_hydrograph", "stage_hydrograph"}
+    bends = [fx for _, fx, m in CASES if m.get("bends")]
+    assert len(bends) == 8 and all(np.max(np.abs(fx["geo_curvature"])) > 2e-5 for fx in bends)       # the curvature term is live there
     assert max(int(fx["iters"].max()) for _, fx, _ in CASES) >= 40          # hard levels are in it
 
 
