@@ -194,6 +194,60 @@ def test_random_reach_against_the_oracle(seed):
     assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
 
 
+def tidal_problem(seed):
+    """a mild reach whose downstream stage rises fast enough to push water back up the channel: the flow changes sign
+    along the reach and in time (Q|Q| in the friction slope, the sign of the advective term, negative boundary flows)"""
+    from synth import normal_depth_rect, normal_depth_trap
+    rng = np.random.default_rng(990000 + seed)
+    N = int(rng.choice([9, 33, 64, 65, 129, 256, 400]))
+    trapezoid = bool(rng.integers(0, 2))
+    b = float(rng.uniform(20.0, 200.0)); m = float(rng.uniform(1.0, 2.5)) if trapezoid else 0.0
+    n = float(rng.uniform(0.02, 0.04)); S0 = float(np.exp(rng.uniform(np.log(3e-5), np.log(2e-4))))
+    Qb = float(rng.uniform(0.05, 0.3)) * b
+    dx = float(rng.uniform(200.0, 800.0)); dt = float(rng.uniform(120.0, 600.0)); theta = float(rng.uniform(0.6, 1.0))
+    hn = normal_depth_trap(b, m, n, S0, Qb) if trapezoid else normal_depth_rect(b, n, S0, Qb)
+    L = (N - 1) * dx
+    geo = {k: np.zeros(N) for k in O.GEO_KEYS}
+    geo["b_main"][:] = b; geo["m_main"][:] = m
+    geo["n_main"][:] = n; geo["n_left"][:] = n; geo["n_right"][:] = n
+    geo["z_bed"] = S0 * L * (1 - np.arange(N) / (N - 1))
+    nt = 9
+    rise = float(rng.uniform(0.5, 1.5))
+    tide = hn * (1.0 + rise * np.sin(np.pi * np.arange(nt) / (nt - 1)) ** 2)
+    us = O.BC("flow_hydrograph", bed_level=S0 * L, target=np.full(nt, Qb))
+    ds = O.BC("stage_hydrograph", bed_level=0.0, target=tide)
+    p = O.Problem(geo=geo, h0=np.full(N, hn), Q0=np.full(N, Qb), us=us, ds=ds, theta=theta, dt=dt, dx=dx, nt=nt, tol=1e-6)
+    return p, dict(N=N, trapezoid=trapezoid, b=b, Qb=Qb, hn=hn, rise=rise, dt=dt, dx=dx, seed=seed)
+
+
+_reversed = []
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_flow_reversal_against_the_oracle(seed):
+    from fixture_batch import batch_from_problems
+    from oracle import c_oracle as CO
+    p, info = tidal_problem(seed)
+    ref = CO.run(p)
+    if ref["status"] != 0:
+        pytest.skip(f"the oracle does not get through this draw: {info}")
+    _reversed.append(bool(np.min(ref["flow"]) < -0.05 * info["Qb"]))
+    for mode in (("trap_uniform",) if info["trapezoid"] else ("rect_uniform", "table")):
+        with batch_from_problems([p], mode=mode, history=True) as b:
+            b.step(p.nt - 1)
+            assert np.all(b.status() == 0), (b.status(), info)
+            h, Q = b.history_arrays(0, p.nt)
+            its = b.iterations(0, p.nt)[:, 0]
+        assert rel_err(h[:, 0], ref["depth"], 1e-3 * info["hn"]) <= TOL and rel_err(Q[:, 0], ref["flow"], 1e-3 * info["Qb"]) <= TOL, info
+        assert np.array_equal(its, ref["iters"]), info
+
+
+def test_the_tide_does_reverse_the_flow():
+    if len(_reversed) < 12:
+        pytest.skip("runs after the tidal cases")
+    assert sum(_reversed) >= len(_reversed) // 2, _reversed
+
+
 def test_most_draws_are_solvable():
     """the sweep means something only if the reference's algorithm itself gets through most of it"""
     if len(_solved) < N_CASES or len(_solved_table) < N_TABLE:
