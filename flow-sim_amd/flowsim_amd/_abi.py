@@ -122,7 +122,7 @@ def device_count():
     return lib().fs_device_count()
 
 
-KERNEL_FIELDS = ("dtype", "section_mode", "cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag", "pivoted")
+KERNEL_FIELDS = ("dtype", "section_mode", "cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag", "reserved")
 
 
 def kernel_table():

@@ -254,7 +254,7 @@ int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_
  * entry i described by out[8] = dtype, section_mode, cells per lane M, waves per reach W, full (1: only
  * N-1 in {64*W*M-1, 64*W*M}), boundary class (-1 any kind, 0 any but FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW,
  * 1 closed-form rectangular rows, 2+k flow hydrograph upstream and kind k downstream), diag (0: compiled
- * without history / trace stores), pivoted (1: the re-solve kernels with 2x2 pivot choice).  The environment
+ * without history / trace stores), one reserved slot (0).  The environment
  * variable FS_KERNEL_INDEX=i makes fs_batch_step use entry i or fail if it does not fit the batch (tests:
  * every instantiation is checked against the oracle). fs_batch_kernel_index: the entry the last step used. */
 int32_t fs_kernel_table_size(void);

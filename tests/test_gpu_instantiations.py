@@ -39,7 +39,7 @@ TABLE = _table()
 def _id(e):
     sec = ("rect", "trap", "table", "irr")[e["section_mode"]]
     return (f"{e['index']:03d}-{'f64' if e['dtype'] == 0 else 'f32'}-{sec}-{e['cells_per_thread']}x{e['waves_per_reach']}"
-            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-piv' if e['pivoted'] else ''}")
+            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}")
 
 
 def _nodes(e):
