@@ -85,6 +85,12 @@
 #ifndef FS_PHASE_FENCE_F32
 #define FS_PHASE_FENCE_F32 8   // the same switch for the fp32 instantiations (three waves per SIMD at 168 registers: the fence keeps them there)
 #endif
+// table kernels with 2 rows per lane: the section parameters of the lane's three nodes are loaded once per launch instead of
+// at every node evaluation (46 vector loads per Newton iteration, their latency only half hidden by the second wave of the
+// SIMD): C4 +8.5 %, the general table kernel +11.6 %, still within the 256-register cap (20 spilled registers)
+#ifndef FS_REG_GEO
+#define FS_REG_GEO 1
+#endif
 #ifndef FS_FLAT_BC
 #define FS_FLAT_BC 1     // kernels compiled for a boundary pair evaluate the two rows in every lane, without a branch (below)
 #endif
@@ -364,6 +370,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   // Short general-section kernels keep (A, Se, Q/A) of every node of the current fold in LDS: if the iterate is accepted they
   // are the node terms of level k, and the level constants of level k+1 come from them instead of from another pass over the
   // sections (1 of 6 section passes of the polyline ensemble, 1 of 11 of C4)
+  constexpr bool kRegGeo = FS_REG_GEO && SEC == FS_SEC_TABLE && W == 1 && M <= 2;
   constexpr bool kFlatBC = FS_FLAT_BC && BCK >= 2 && sizeof(R) == 8 && SEC == FS_SEC_TRAP_UNIFORM;   // measured: C5 fp64 +1.5 %; flagship -1.5 %, C4 -7 %, polyline -1.3 %
   constexpr bool kSaveTerms = FS_SAVE_TERMS && !Geometry<R, SEC>::kConstT && (M <= 2 || (sizeof(R) == 8 && M <= FS_SAVE_TERMS_MAXM_F64));
   __shared__ Smem<R, M, W, kSaveTerms> sm;
@@ -386,6 +393,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
   Geo geo;
   geo.init(a, reach);
+  // node terms of the lane's local node j (0..M); FS_REG_GEO: from section parameters loaded once per launch
+  SecParams<R> secs[kRegGeo ? M + 1 : 1];
+  if constexpr (kRegGeo) {
+#pragma unroll
+    for (int j = 0; j <= M; ++j) secs[j] = geo.section(min(s0 + j, N - 1));
+  }
+  auto terms_at = [&](int j, R hh, R QQ) {
+    if constexpr (kRegGeo) return node_terms_general(secs[j], hh, QQ);
+    else return geo.terms(min(s0 + j, N - 1), hh, QQ);
+  };
 
   const R th = a.theta, dt = a.dt;
   R r2dt = R(1) / (R(2) * dt);
@@ -420,16 +437,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     NodeTerms<R> r;
     r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eAT = rol(first.eAT); r.eQ = rol(first.eQ); r.v = rol(first.v);
     r.rT = rol(first.rT);
-    if (NC >= 64 * M - 1 && lane == 63) r = geo.terms(min(s0 + M, N - 1), hM, QM);
+    if (NC >= 64 * M - 1 && lane == 63) r = terms_at(M, hM, QM);
     return r;
   };
   auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
-    NodeTerms<R> L = geo.terms(min(s0, N - 1), hh[0], QQ[0]);
+    NodeTerms<R> L = terms_at(0, hh[0], QQ[0]);
     NodeTerms<R> Rlast;
     if (kShareNode) Rlast = last_node_terms(L, hh[M], QQ[M]);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
+      const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : terms_at(c + 1, hh[c + 1], QQ[c + 1]);
       const R sumA = L.A + Rn.A;
       // explicit fmas only (no a*b + c left to the compiler's choice: see FS_PRIME)
       sm.kc[0][c][t] = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
@@ -618,7 +635,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       R upU1 = R(0), upU3 = R(0), upRu = R(0);    // the lane's finished up row, kept for the way back
       R rcLast = R(0);                            // rc of the lane's last row (links node M: p_M = rc - m_{M-1})
       {
-        NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+        NodeTerms<R> L = terms_at(0, h[0], Q[0]);
         NodeTerms<R> Rlast;
         if (kShareNode) Rlast = last_node_terms(L, h[M], Q[M]);
         save_terms(0, L);
@@ -632,7 +649,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #pragma unroll
         for (int c = 0; c < M; ++c) {
           const R k0 = kcb[(0 * M + c) * T], k1 = kcb[(1 * M + c) * T], k2 = kcb2[(0 * M + c) * T], k3 = kcb2[(1 * M + c) * T];
-          const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+          const NodeTerms<R> Rn = (kShareNode && c == M - 1) ? Rlast : terms_at(c + 1, h[c + 1], Q[c + 1]);
           save_terms(c + 1, Rn);
           const R i2tR = dt * Rn.rT;
           if (!Geo::kConstT) iTn[c + 1] = i2tR;
@@ -938,10 +955,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         FS_T(9);
         if (kSaveTerms) {                                             // level constants of the next level
           if (prime) {                           // no fold has run yet: the node terms of the entry state go where a fold leaves them
-            NodeTerms<R> L = geo.terms(min(s0, N - 1), h[0], Q[0]);
+            NodeTerms<R> L = terms_at(0, h[0], Q[0]);
             save_terms(0, L);
 #pragma unroll
-            for (int c = 0; c < M; ++c) save_terms(c + 1, geo.terms(min(s0 + c + 1, N - 1), h[c + 1], Q[c + 1]));
+            for (int c = 0; c < M; ++c) save_terms(c + 1, terms_at(c + 1, h[c + 1], Q[c + 1]));
           }
           level_constants_from_saved(h, Q);
         } else {
