@@ -83,6 +83,7 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
   X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_NORMAL_DEPTH)) \
   X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)) \
+  X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER)) \
   X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND)) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \

@@ -78,7 +78,7 @@ def test_c3_flagship_kernel_at_4096_nodes_against_the_reference():
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_c5_kernel_at_512_nodes_against_the_reference(dtype):
     """BASELINE configs[4] shape: simple trapezoid, 512 nodes, power rating curve downstream, no history: the
-    <R, TRAP_UNIFORM, 8, 1, full, rating power> instantiations (fp64: DIAG = false).  fp32 is the throughput mode:
+    <R, TRAP_UNIFORM, 8, 1, full, rating power, DIAG = false> instantiations.  fp32 is the throughput mode:
     tolerance 1e-3, hydrographs within 5e-4 of the fp64 reference."""
     from flowsim_amd import BoundarySpec, PreissmannBatch
     from flowsim_amd import _abi as A
@@ -102,7 +102,7 @@ def test_c5_kernel_at_512_nodes_against_the_reference(dtype):
         assert np.all(b.status() == 0)
         e = entry_of(b)
         assert (e["cells_per_thread"], e["waves_per_reach"], e["full"]) == (8, 1, 1)
-        assert e["boundary_class"] == 2 + A.BC_RATING_POWER and e["diag"] == (0 if dtype == "f64" else 1)
+        assert e["boundary_class"] == 2 + A.BC_RATING_POWER and e["diag"] == 0
         if dtype == "f64":
             for j in range(B):
                 check_rows(b, fx["depth"][j], fx["flow"][j], fx["iters"][j], j)
