@@ -181,8 +181,9 @@ def test_random_reach_against_the_oracle(seed):
     p, info = random_problem(seed)
     if info["froude"] >= 0.9:
         # supercritical base flow: one boundary condition at each end is not what such a flow takes, the Newton systems are
-        # ill-conditioned and the two CPU oracles themselves (pivoted LU in C, SuperLU in numpy) part by 1e-4 there (found by
-        # a soak run of 8 000 draws: 4 such cases); the reference's own set-up refuses supercritical profiles (channel.py:329)
+        # ill-conditioned (cond up to 3e15) and the time stepping amplifies rounding differences tenfold per level: the two CPU
+        # oracles themselves (pivoted LU in C, SuperLU in numpy) part by 1e-4 there (a soak run of 8 000 draws found 4 such
+        # cases); the reference's own set-up refuses supercritical profiles (channel.py:329)
         _solved.append(True)
         pytest.skip(f"supercritical draw (Fr = {info['froude']:.2f}): outside the scheme's domain")
     ref = CO.run(p)
