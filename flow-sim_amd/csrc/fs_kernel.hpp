@@ -594,8 +594,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         // Boundary kinds fixed at compile time: EVERY lane evaluates both rows, on its own numbers, as straight-line code;
         // only lane 0 / the lane of node N-1 keep what comes out.  A wave executes a divergent branch for one lane at the
         // price of all 64 anyway - but a branch is a block of its own, and the row's dependent chain (a pow, a conveyance)
-        // then runs alone at dependent-issue latency ahead of the fold (10 - 16 % of an iteration of the one-wave-per-SIMD
-        // kernels); as straight-line code it is scheduled into the first cell's independent work.
+        // then runs alone at dependent-issue latency ahead of the fold; as straight-line code it is scheduled into the first
+        // cell's independent work.  Pays only in the one-wave-per-SIMD trapezoid kernel (C5 fp64 +2 %), see kFlatBC.
         R dummy = R(0), YnewAll = Yprev;
         int fU = 0, fD = 0;
         Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &fU);
@@ -610,20 +610,20 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           if (fD) sm.xflag[parity] = fD;
         }
       } else {
-      if (t == 0) {
-        R dummy; int flag = 0;
-        Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
-        nrm2 = Urow.res * Urow.res;
-      }
-      if (t == tD) {
-        R hD = h[0], QD = Q[0];
-        int flag = 0;
+        if (t == 0) {
+          R dummy; int flag = 0;
+          Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+          nrm2 = Urow.res * Urow.res;
+        }
+        if (t == tD) {
+          R hD = h[0], QD = Q[0];
+          int flag = 0;
 #pragma unroll
-        for (int j = RAGGED ? 1 : M - 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
-        Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
-        nrm2 += Drow.res * Drow.res;
-        if (flag) sm.xflag[parity] = flag;
-      }
+          for (int j = RAGGED ? 1 : M - 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+          Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+          nrm2 += Drow.res * Drow.res;
+          if (flag) sm.xflag[parity] = flag;
+        }
       }
       FS_T(1);
 
