@@ -48,11 +48,23 @@ def props(geo, hw):
     return A, P, R, T, over
 
 
+def _pw(x, p):
+    """x ** p as the reference's scalar code gets it: for single values (what the section objects pass, one node at a time)
+    Python's pow, i.e. libm.  numpy's array loop rounds about one result in twenty differently (1 ulp) - harmless by itself, but
+    the brentq behind normal_depth then stops one ulp away and an unstable GVF march (explicit steps on a steep reach) blows
+    that up to percents.  Whole-ensemble arrays (flowsim_amd.ensemble) keep the vectorised loop."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.size > 8:
+        return np.power(x, p)
+    with np.errstate(all="ignore"):
+        return np.array([float(v) ** p if v >= 0.0 else np.nan for v in x.ravel()], dtype=np.float64).reshape(x.shape)
+
+
 def conveyance(geo, hw, pr=None):
     """Total conveyance; compound sections sum K^1.5 over left / main / right (cross_section.py:741-754)."""
     A, P, R, T, over = pr if pr is not None else props(geo, hw)
     with np.errstate(divide="ignore", invalid="ignore"):
-        K = A * np.power(R, 2.0 / 3.0) / geo["n_main"]
+        K = A * _pw(R, 2.0 / 3.0) / geo["n_main"]
         comp = geo["is_compound"] > 0.5
         if np.any(comp):
             z, b, m, hb, mf = geo["z_bed"], geo["b_main"], geo["m_main"], geo["h_bf"], geo["m_fp"]
@@ -64,11 +76,11 @@ def conveyance(geo, hw, pr=None):
             P_m = b + 2.0 * hb * np.sqrt(1.0 + m * m)
             A_l = (geo["b_fp_l"] + 0.5 * mf * dfp) * dfp; P_l = geo["b_fp_l"] + dfp * sf
             A_r = (geo["b_fp_r"] + 0.5 * mf * dfp) * dfp; P_r = geo["b_fp_r"] + dfp * sf
-            k = lambda a, n, p: a * np.power(np.where(p > 0, a / np.where(p > 0, p, 1.0), 0.0), 2.0 / 3.0) / n
+            k = lambda a, n, p: a * _pw(np.where(p > 0, a / np.where(p > 0, p, 1.0), 0.0), 2.0 / 3.0) / n
             K_m = np.where(over, k(A_m, geo["n_main"], P_m), K)
             K_l = np.where(over, k(A_l, geo["n_left"], P_l), 0.0)
             K_r = np.where(over, k(A_r, geo["n_right"], P_r), 0.0)
-            K = np.where(comp, np.power(np.power(K_l, 1.5) + np.power(K_m, 1.5) + np.power(K_r, 1.5), 2.0 / 3.0), K)
+            K = np.where(comp, _pw(_pw(K_l, 1.5) + _pw(K_m, 1.5) + _pw(K_r, 1.5), 2.0 / 3.0), K)
     return K
 
 
@@ -80,7 +92,7 @@ def equivalent_n(geo, hw, pr=None, K=None):
     if np.any(comp):
         K = conveyance(geo, hw, (A, P, R, T, over)) if K is None else K
         with np.errstate(divide="ignore", invalid="ignore"):
-            neq = A * np.power(R, 2.0 / 3.0) / K
+            neq = A * _pw(R, 2.0 / 3.0) / K
         n = np.where(comp & (A > 0) & (R > 0) & (K > 0), neq, n)
     return n
 

@@ -249,7 +249,11 @@ def main():
     ap.add_argument("--storage", type=int, default=12)
     ap.add_argument("--bends", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20260301)
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "random_sweep.npz"),
+                    help="a soak run writes elsewhere (e.g. gpurun_out/sweep_soak.npz, FS_SWEEP_FIXTURE for the tests)")
     a = ap.parse_args()
+    out_path = os.path.abspath(a.out)              # before the chdir below: nothing is ever written under /root/reference
+    assert not out_path.startswith("/root/reference")
     sys.dont_write_bytecode = True
     os.environ.setdefault("MPLBACKEND", "Agg")
     os.chdir("/root/reference")
@@ -261,6 +265,7 @@ def main():
     arrays, metas, tried, t0 = {}, [], 0, time.time()
     rng_store = np.random.default_rng(a.seed + 2)
     rng_bend = np.random.default_rng(a.seed + 3)
+    width = 2 if a.cases + a.polyline + a.storage + a.bends <= 100 else 4
     total = a.cases + a.polyline + a.storage + a.bends
     while len(metas) < total and tried < 6 * total:
         tried += 1
@@ -280,7 +285,7 @@ def main():
         for k in ("R0", "norm_level", "norm_value", "final_unknowns"):
             out.pop(k, None)
         for k, v in out.items():
-            arrays[f"c{i:02d}_{k}"] = v
+            arrays[f"c{i:0{width}d}_{k}"] = v
         m = base_meta(sol, 1e-6, wall, **extra)
         m.update(family=recipe["family"], n_sections=len(recipe["chain"]), us_kind=recipe["us_kind"], ds_kind=recipe["ds_kind"],
                  ic=recipe["ic"], Qb=recipe["Qb"], amp=recipe["amp"], bends="coords" in recipe, recipe=recipe)
@@ -289,7 +294,7 @@ def main():
               f"ic={m['ic']:12s} its={out['iters'][1:].tolist()}")
     meta = dict(generator="oracle/gen_random_sweep.py", reference="cve-mohd/flow-sim snapshot 2026-02-13, run in the build container",
                 seed=a.seed, draws=tried, cases=metas)
-    path = os.path.join(ROOT, "tests", "golden", "random_sweep.npz")
+    path = out_path
     np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB): {len(metas)} cases of {tried} draws in {time.time() - t0:.0f} s")
 

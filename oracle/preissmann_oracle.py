@@ -604,6 +604,7 @@ def sweep_cases(path):
     """(index, arrays, meta) of every case of a multi-case fixture (oracle/gen_random_sweep.py: arrays of case i stored
     as c{i:02d}_<name>, metadata in meta["cases"][i]); each pair goes through problem_from_fixture like a single fixture"""
     fx, meta = load_fixture(path)
+    width = 2 if len(meta["cases"]) <= 100 else 4
     for i, m in enumerate(meta["cases"]):
-        pre = f"c{i:02d}_"
+        pre = f"c{i:0{width}d}_"
         yield i, {k[len(pre):]: fx[k] for k in fx.files if k.startswith(pre)}, m
