@@ -50,9 +50,9 @@ def library_sha256():
 
 def load_profile(workload, dtype, N, entry):
     """HBM traffic / flop counts of this workload's step kernel from the committed rocprofv3 PMC passes
-    (profiles/round2/<workload>_<dtype>.json, tools/refresh_profiles.py) - only if they were taken on the very library
+    (profiles/round3/<workload>_<dtype>.json, tools/refresh_profiles.py) - only if they were taken on the very library
     that is loaded now and on the same instantiation; a stale file gives None (traffic: null) rather than a wrong number."""
-    path = os.path.join(ROOT, "profiles", "round2", f"{workload}_{dtype}.json")
+    path = os.path.join(ROOT, "profiles", "round3", f"{workload}_{dtype}.json")
     if not os.path.exists(path):
         return None
     p = json.load(open(path))
@@ -61,6 +61,21 @@ def load_profile(workload, dtype, N, entry):
         return None
     p["file"] = os.path.relpath(path, ROOT)
     return p
+
+
+def traffic_of_launch(prof, B, K):
+    """HBM bytes of ONE launch of K levels over B reaches.  The step kernel reads the state once per launch and writes it
+    back once per launch, whatever K is; only the boundary targets, hydrograph rows and Newton counts
+    scale with K.  The profile therefore keeps the two parts apart (two rocprofv3 runs at different K give both,
+    tools/refresh_profiles.py --second): traffic = fixed * B + per_level * B * K.  A profile that only has a per-launch
+    figure is used for exactly its own K and nothing else."""
+    if prof is None:
+        return None
+    if "hbm_bytes_per_reach_fixed" in prof:
+        return (prof["hbm_bytes_per_reach_fixed"] + prof["hbm_bytes_per_reach_per_level"] * K) * float(B)
+    if prof.get("levels_in_launch") == K and "hbm_bytes_per_reach_timestep" in prof:
+        return prof["hbm_bytes_per_reach_timestep"] * float(B) * K
+    return None
 
 
 def cpu_baseline(N, dt, dx, theta, tol, budget_s=9.0, compiled=False):
@@ -357,6 +372,20 @@ def main():
         dist.all_reduce(kms_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(it_t, op=dist.ReduceOp.SUM)
     el = float(el_t.item()); kern_ms_max = float(kms_t.item())
+    # who took part: one row per rank as the collective saw it (rank, device ordinal, PCI bus id, its kernel time, its reaches)
+    try:
+        bus = int(str(torch.cuda.get_device_properties(local).pci_bus_id))
+    except Exception:
+        bus = -1
+    mine = torch.tensor([float(rank), float(local), float(bus), float(kern_ms), float(B), float(first)], dtype=torch.float64,
+                        device=f"cuda:{local}" if (world == 1 or args.backend == "nccl") else "cpu")
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    ranks = [dict(rank=int(r[0]), device=int(r[1]), pci_bus_id=int(r[2]), kernel_ms=float(r[3]), reaches=int(r[4]), first_reach=int(r[5]))
+             for r in (x.cpu().tolist() for x in rows)]
     info = batch.kernel_info()
     kidx = batch.kernel_index()
 
@@ -380,11 +409,12 @@ def main():
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
                        "status_counts_rank0": status_counts,
                        "kernel": dict(info, table_index=kidx, boundary_class=entry["boundary_class"], full=entry["full"], diag=entry["diag"]),
-                       "kernel_ms_max_over_ranks": kern_ms_max},
+                       "kernel_ms_max_over_ranks": kern_ms_max,
+                       "collective_world_size": dist.get_world_size() if world > 1 else 1, "ranks": ranks},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None if prof is None else prof["hbm_bytes_per_reach_timestep"] * float(B) * K,
-                         "traffic_source": None if prof is None else prof["file"] + ": " + prof["traffic_note"],
+                         "traffic": traffic_of_launch(prof, B, K),
+                         "traffic_source": None if traffic_of_launch(prof, B, K) is None else prof["file"] + ": " + prof["traffic_note"],
                          "kernel": "preissmann_step_kernel", "kernel_ms": kern_ms, "launches": 1,
                          "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
                          "note": "fp64-VALU bound, not HBM bound: see DESIGN.md section 4"},

@@ -79,6 +79,7 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
+                          FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
@@ -162,6 +163,7 @@ struct fs_batch {
   bool iterating = false;     // a level opened by fs_batch_iterate has not been closed yet
   int launches = 0;
   int level = 0;
+  int restart_level = 0;      // > 0: the batch was re-seeded at this level (fs_batch_restart); history rows 1 .. restart_level-1 are empty
   const Entry *kern = nullptr;
   // scheme
   double theta = 0.6, dt = 0, dx = 0, tol = 1e-4;
@@ -265,7 +267,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
 int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
   std::string why;
   const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
-                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE)) != 0, &why, iter_budget > 0);
+                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE | FS_FLAG_MONITOR)) != 0, &why, iter_budget > 0);
   if (!k && why.rfind("FS_KERNEL_INDEX", 0) == 0) return fail("fs_batch_step: " + why);
   if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
     return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
@@ -545,7 +547,7 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream));
   if (b->trace) HIP_TRY(hipMemsetAsync(b->trace, 0, (size_t)b->d.max_levels * FS_TRACE_CAP * B * b->esz, b->stream));
   HIP_TRY(hipMemsetAsync(b->it_done, 0, B * 4, b->stream));
-  b->level = 0; b->iterating = false;
+  b->level = 0; b->iterating = false; b->restart_level = 0;
   b->have_state = true;
   return 0;
 }
@@ -573,7 +575,7 @@ int fs_batch_set_state_uniform(fs_batch *b, const double *h, const double *Q) {
   HIP_TRY(hipMemsetAsync(b->it_done, 0, B * 4, b->stream));
   if (b->trace) HIP_TRY(hipMemsetAsync(b->trace, 0, (size_t)b->d.max_levels * FS_TRACE_CAP * B * b->esz, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  b->level = 0;
+  b->level = 0; b->iterating = false; b->restart_level = 0;
   b->have_state = true;
   return 0;
 }
@@ -610,7 +612,7 @@ int fs_batch_iterate(fs_batch *b, int32_t *n_open) {
   HIP_TRY(hipMemcpy(done.data(), b->it_done, B * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(st.data(), b->status, B * 4, hipMemcpyDeviceToHost));
   int32_t open = 0;
-  for (size_t r = 0; r < B; ++r) open += (done[r] >= 0 && st[r] == FS_OK) ? 1 : 0;
+  for (size_t r = 0; r < B; ++r) open += (done[r] >= 0 && (st[r] == FS_OK || st[r] == FS_ILL_CONDITIONED)) ? 1 : 0;   // (a warning, not a failure)
   if (open == 0) {      // every reach has accepted the level (or failed on it): next level, counters back to zero
     b->level += 1;
     b->iterating = false;
@@ -647,6 +649,9 @@ int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *
                      const double *storage_stage) {
   if (!b || !h || !Q || !h_guess || !Q_guess) return fail("fs_batch_restart: null argument");
   if (level < 0 || level + 1 >= b->d.max_levels) return fail("fs_batch_restart: level out of range");
+  if (level > 0 && !storage_stage && b->have_bc[FS_DOWNSTREAM] && fs::bc_is_storage(b->bc_kind[FS_DOWNSTREAM]))
+    return fail("fs_batch_restart: a storage boundary continues from the reservoir stage of `level` (storage_stage[B], "
+                "fs_batch_get_storage_stage); without it the run would go on from stage 0");
   if (fs_batch_set_state(b, h, Q)) return -1;
   FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches, N = b->d.n_nodes;
@@ -660,7 +665,7 @@ int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
   }
-  b->level = level;
+  b->level = level; b->restart_level = level;
   return 0;
 }
 
@@ -718,6 +723,8 @@ int fs_batch_get_history(fs_batch *b, int32_t first, int32_t n, double *h, doubl
   FS_ON_DEVICE(b);
   if (!b->hist_h) return fail("fs_batch_get_history: batch was created without FS_FLAG_HISTORY");
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_get_history: level range out of bounds");
+  if (b->restart_level > 0 && first < b->restart_level)
+    return fail("fs_batch_get_history: this batch was restarted at level " + std::to_string(b->restart_level) + "; the history before it was not restored");
   const size_t per = (size_t)b->d.n_reaches * b->d.n_nodes;
   return download(b, h, b->hist_h, first * per, n * per) || download(b, Q, b->hist_Q, first * per, n * per) ? -1 : 0;
 }
@@ -750,6 +757,9 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
   if (!b->hist_h) return fail("fs_batch_derive: batch was created without FS_FLAG_HISTORY");
   if (first < 0 || n < 1 || first + n > b->d.max_levels) return fail("fs_batch_derive: level range out of bounds");
   if ((fields & FS_DERIVE_ALL) == 0) return fail("fs_batch_derive: no field requested");
+  if (b->restart_level > 0 && first < b->restart_level)
+    return fail("fs_batch_derive: this batch was restarted at level " + std::to_string(b->restart_level) +
+                "; the history before it was not restored (row 0 holds the restart state, which amplitudes then refer to)");
   FS_ON_DEVICE(b);
   const size_t BN = (size_t)b->d.n_reaches * b->d.n_nodes;
   void *dev[8] = {nullptr};

@@ -859,6 +859,13 @@ template <int D, typename R> __device__ __forceinline__ Seg<R> seg_from_below(co
   o.rd = tree_from_below<D>(s.rd); o.rc = tree_from_below<D>(s.rc);
   return o;
 }
+// the value lane `src` holds, in every lane (src: wave-uniform - a constant or a scalar register)
+__device__ __forceinline__ double read_lane(double v, int src) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+__device__ __forceinline__ float read_lane(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 template <int CTRL, int ROWS, int BANKS> __device__ __forceinline__ int dpp_zero(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, BANKS, true);     // lanes without a source (or masked off) get 0
 }

@@ -97,8 +97,17 @@
 #ifndef FS_LAUNDER_BACK
 #define FS_LAUNDER_BACK 1
 #endif
+#ifndef FS_MONITOR_ALL
+#define FS_MONITOR_ALL 0   // 1: the conditioning monitor (below) also in the kernels compiled without diagnostics (DIAG = false); measured
+#endif                     // cost on the flagship: profiles/round3/README.md
+#ifndef FS_XLANES_MINW
+#define FS_XLANES_MINW 8 // waves per reach from which the cross-wave step runs as a second, small DPP tree (lane w of every wave carries
+#endif                   // the segment of wave w: 8 live numbers) instead of every thread folding all W segments in its own registers
+                         // (16 W live doubles).  Measured on 65 536 x 4 096 (profiles/round3/second_wave_per_simd.md): W = 8 (the (8, 8)
+                         // shape, two waves per SIMD) 7.9e6 -> 9.8e6 (the per-thread fold spills at 256 registers); W = 4 (the flagship
+                         // (16, 4) shape) 1.072e7 -> 1.058e7: with four segments the per-thread fold has the shorter dependent chain
 #ifndef FS_PRIME
-#define FS_PRIME 0       // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
+#define FS_PRIME 0      // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
 #endif                   // through it) instead of from a second instance of that code ahead of the loop.  Not needed: with
                          // -ffp-contract=on (Makefile) the two instances compile to the same arithmetic and chunked stepping equals
                          // one launch bit for bit (tests/test_gpu_parity.py, test_gpu_dropin.py); flagship -5.5 %; kept as a switch
@@ -120,6 +129,21 @@ namespace fs {
 
 template <typename R> __host__ __device__ constexpr R finite_max() { return sizeof(R) == 8 ? R(1.7976931348623157e308) : R(3.4028234e38); }
 template <typename R> __host__ __device__ constexpr R eps_of() { return sizeof(R) == 8 ? R(2.220446049250313e-16) : R(1.1920929e-7); }
+
+// Conditioning monitor.  The up row of a segment [a, b) reads  u1 p_a + m_a + u3 m_{b-1} = ru : u3 is the product of
+// -(super-diagonal / pivot) over the segment's rows, i.e. how strongly the first unknown of the segment depends on its last
+// one.  Subcritical, the rows are diagonally dominant and |u3| decays along the reach (typically 0.2 ... 0.6 over a whole
+// reach); with v > c the upstream-travelling characteristic turns round, |u3| grows geometrically with the length of the
+// segment, the two-point boundary value problem (one condition per end, boundary.py) is ill-posed and the Jacobian the
+// reference hands to SuperLU is ill-conditioned (cond 1e13 ... 1e16 on the draws of profiles/round2/supercritical_scan.txt
+// that part from the pivoted CPU solvers).  The kernel keeps the largest |u3| of any segment the tree forms - one integer
+// (the high word of the magnitude) carried along with the segment - and raises FS_ILL_CONDITIONED above 2^10 (calibration:
+// DESIGN.md section 4.1; every reference-generated near-critical fixture the kernel misses by more than 1e-8 lies above): the reference's
+// `diagnos` check (preissmann.py:139-144, rcond < 1e-12 -> ValueError "Jacobian is ill-conditioned") stands behind it.
+__device__ __forceinline__ int hi_abs(double v) { return __double2hiint(v) & 0x7fffffff; }
+__device__ __forceinline__ int hi_abs(float v) { return __float_as_int(v) & 0x7fffffff; }
+template <typename R> __host__ __device__ constexpr int growth_limit_bits() { return sizeof(R) == 8 ? ((1023 + 10) << 20) : ((127 + 10) << 23); }
+__device__ __forceinline__ int max_(int a, int b) { return a > b ? a : b; }
 
 template <typename R> struct KernelArgs {
   int32_t B, N, n_steps, level0, max_iter;
@@ -335,6 +359,7 @@ template <typename R, int M, int W, bool SAVE> struct Smem : SavedTerms<R, M, 64
   R xbc[2][4];             // upstream boundary row on (p_0, m_0): aU, bU, rU
   R bcp[2][FS_BC_MAX_PARAMS];   // this reach's boundary parameters (fixed-size kinds), read every Newton iteration
   R xnorm[2][W];
+  int32_t xg[2][W];        // conditioning monitor: high word of the largest |u3| of each wave's tree
   int32_t xflag[2];
 };
 
@@ -514,6 +539,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(a.ds.kind);
   R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
+  // FS_ILL_CONDITIONED is a warning that sticks to the reach, not a failure: the run goes on (and a later launch finds it here)
+  constexpr bool kMonitor = DIAG || FS_MONITOR_ALL;
+  bool warn = status == FS_ILL_CONDITIONED;
+  if (warn) status = FS_OK;
   bool primed = false;                        // (h, Q) hold the Newton vector (after the priming pass), not the entry state
   int parity = 0;
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
@@ -712,6 +741,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         seg.rc = rcPrev; rcLast = rcPrev;
         upU1 = seg.u1; upU3 = seg.u3; upRu = seg.ru;
       }
+      int gi = 0;                                  // conditioning monitor: largest |u3| of the segments this lane has seen
+      if constexpr (kMonitor) gi = hi_abs(seg.u3);
 
       FS_T(0);
 #if FS_PHASE_FENCE & 1
@@ -730,6 +761,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           p[0 * 64] = e.A1; p[1 * 64] = e.A2; p[2 * 64] = e.A3; p[3 * 64] = e.rc;
         }
         seg = mg;      // in every lane: a lane that does not survive this level is not read again (no select, no branch around the merge)
+        if constexpr (kMonitor) gi = max_(max_(tree_from_below<d>(gi), gi), hi_abs(mg.u3));
       };
       up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
       up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
@@ -742,6 +774,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         R *p = sm.xseg[parity][wave];
         p[0] = seg.u1; p[1] = seg.u3; p[2] = seg.ru; p[3] = seg.d1; p[4] = seg.d2; p[5] = seg.d3; p[6] = seg.rd; p[7] = seg.rc;
         sm.xnorm[parity][wave] = nrm2;
+        if constexpr (kMonitor) sm.xg[parity][wave] = gi;
       }
       FS_T(2);
       __syncthreads();
@@ -751,6 +784,67 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       R tot = R(0);
       R pL, mR;                        // p of this wave's first row, m of its last one
       R mAw = R(0), mBw = R(0);        // m of this wave's first row / of the next wave's first row (shared nodes, below)
+      if constexpr (W > 1 && W >= FS_XLANES_MINW) {
+        // A second, small tree over the W wave segments, one segment per LANE: lane w of every wave takes the segment of
+        // wave w and the W - 1 merges run as log2 W DPP levels (row_shr:1/2/4) exactly like the in-wave tree - the same
+        // merges in the same order as the per-thread fold below, so the bits do not change - with 8 live numbers per lane
+        // instead of 16 W.  Every wave does it redundantly on its own copy of the records (no second barrier).
+        constexpr int LW = W == 2 ? 1 : (W == 4 ? 2 : 3);
+        static_assert(W == 2 || W == 4 || W == 8, "cross-wave tree: 2, 4 or 8 waves per reach");
+        const int wl = ln & (W - 1);
+        const R *ps = sm.xseg[parity][wl];
+        Seg<R> xs;
+        xs.u1 = ps[0]; xs.u3 = ps[1]; xs.ru = ps[2]; xs.d1 = ps[3]; xs.d2 = ps[4]; xs.d3 = ps[5]; xs.rd = ps[6]; xs.rc = ps[7];
+        const R u1o = xs.u1, u3o = xs.u3, ruo = xs.ru;       // the wave's own up row (m of its first row, below)
+#pragma unroll
+        for (int w = 0; w < W; ++w) tot += sm.xnorm[parity][w];
+        int gx = 0;
+        if constexpr (kMonitor) gx = sm.xg[parity][wl];
+        // Records stay in registers (valid in the lane that survives its level: low l + 1 bits set); on the way down the
+        // group's record comes from the group's last lane by a quad permute (groups of 2 and 4 lanes) or a readlane (8).
+        Elim<R> xe[LW];
+        auto xup = [&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          constexpr int d = 1 << l;
+          if constexpr (l < LW) {
+            const Seg<R> left = seg_from_below<d>(xs);
+            Seg<R> mg;
+            merge(left, xs, mg, xe[l]);
+            xs = mg;
+            if constexpr (kMonitor) gx = max_(max_(tree_from_below<d>(gx), gx), hi_abs(mg.u3));
+          }
+        };
+        xup(std::integral_constant<int, 0>{}); xup(std::integral_constant<int, 1>{}); xup(std::integral_constant<int, 2>{});
+        R p0, m0, ml;
+        close_root(xs, sm.xbc[parity][0], sm.xbc[parity][1], sm.xbc[parity][2], p0, m0, ml);     // valid in lane W - 1
+        R px = read_lane(p0, W - 1), mx = read_lane(ml, W - 1);
+        auto xdown = [&](auto lc) {
+          constexpr int l = decltype(lc)::value;
+          if constexpr (l < LW) {
+            Elim<R> e;
+            if constexpr (l == 0) {        // quad_perm:[1,1,3,3]
+              e.A1 = dpp_mov<0xF5>(xe[l].A1); e.A2 = dpp_mov<0xF5>(xe[l].A2); e.A3 = dpp_mov<0xF5>(xe[l].A3); e.rc = dpp_mov<0xF5>(xe[l].rc);
+            } else if constexpr (l == 1) { // quad_perm:[3,3,3,3]
+              e.A1 = dpp_mov<0xFF>(xe[l].A1); e.A2 = dpp_mov<0xFF>(xe[l].A2); e.A3 = dpp_mov<0xFF>(xe[l].A3); e.rc = dpp_mov<0xFF>(xe[l].rc);
+            } else {
+              e.A1 = read_lane(xe[l].A1, 7); e.A2 = read_lane(xe[l].A2, 7); e.A3 = read_lane(xe[l].A3, 7); e.rc = read_lane(xe[l].rc, 7);
+            }
+            const R sep = separator(e, px, mx);
+            const bool upper = ((wl >> l) & 1) != 0;
+            px = upper ? e.rc - sep : px;
+            mx = upper ? mx : sep;
+          }
+        };
+        xdown(std::integral_constant<int, 2>{}); xdown(std::integral_constant<int, 1>{}); xdown(std::integral_constant<int, 0>{});
+        // m of every wave's first row from its own up row: the node there is shared with the wave before, and both
+        // copies must move by the same bits
+        const R max_ = fma_(-u1o, px, fma_(-u3o, mx, ruo));
+        const int ws = __builtin_amdgcn_readfirstlane(wave);
+        pL = read_lane(px, ws); mR = read_lane(mx, ws); mAw = read_lane(max_, ws);
+        mBw = read_lane(max_, (ws + 1) & (W - 1));
+        if (ws == W - 1) mBw = R(0);
+        if constexpr (kMonitor) { if (__builtin_amdgcn_readlane(gx, W - 1) > growth_limit_bits<R>()) warn = true; }
+      } else {
       {
         // pairwise tree over the W wave segments (depth log2 W instead of a serial chain of W-1 merges;
         // the two merges of a level are independent and overlap); every thread does all of it
@@ -764,10 +858,19 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           sw0[w] = sw[w];
           tot += sm.xnorm[parity][w];
         }
+        int gx = 0;
+        if constexpr (kMonitor) {
+#pragma unroll
+          for (int w = 0; w < W; ++w) gx = max_(gx, sm.xg[parity][w]);
+        }
 #pragma unroll
         for (int st = 1; st < W; st *= 2)
 #pragma unroll
-          for (int i = 0; i + st < W; i += 2 * st) merge(sw[i], sw[i + st], sw[i], we[i + st - 1]);
+          for (int i = 0; i + st < W; i += 2 * st) {
+            merge(sw[i], sw[i + st], sw[i], we[i + st - 1]);
+            if constexpr (kMonitor) gx = max_(gx, hi_abs(sw[i].u3));
+          }
+        if constexpr (kMonitor) { if (gx > growth_limit_bits<R>()) warn = true; }
         R pw[W], mw[W], p0, m0, ml;      // pw[w], mw[w]: the two numbers of wave w (valid for the group heads while unfolding)
         close_root(sw[0], sm.xbc[parity][0], sm.xbc[parity][1], sm.xbc[parity][2], p0, m0, ml);
         pw[0] = p0; mw[0] = ml;
@@ -789,6 +892,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #pragma unroll
         for (int w = 1; w < W; ++w)
           if (wave == w) { pL = pw[w]; mR = mw[w]; mAw = ma[w]; mBw = ma[w + 1]; }
+      }
       }
       FS_T(4);
       if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
@@ -994,7 +1098,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     for (int j = 0; j < M; ++j)
       if (!RAGGED || s0 + j < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
   }
-  if (t == 0) a.status[reach] = status;
+  if (t == 0) a.status[reach] = (status == FS_OK && warn) ? (int)FS_ILL_CONDITIONED : status;
   if (ds_storage && t == tD) a.Yprev[reach] = Yprev;
 #ifdef FS_STAMP
   if (a.dbg && lane == 0)

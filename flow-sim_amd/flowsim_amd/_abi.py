@@ -23,8 +23,8 @@ GEO_NPARAM = len(GEO_ROWS)
 SC_NAMES = ("min_stage", "Y_min", "Y_max", "bed_level", "surface_area", "alpha", "beta", "n_curve", "rc_type", "rc_a",
             "rc_b", "rc_c", "rc_shift", "capture_losses", "reservoir_length", "K_q")
 UPSTREAM, DOWNSTREAM = 0, 1
-OK, MAX_ITER, NAN, STORAGE_RANGE = 0, 1, 2, 3
-FLAG_HISTORY, FLAG_TRACE = 1, 2
+OK, MAX_ITER, NAN, STORAGE_RANGE, ILL_CONDITIONED = 0, 1, 2, 3, 4
+FLAG_HISTORY, FLAG_TRACE, FLAG_MONITOR = 1, 2, 4
 TRACE_CAP = 64
 DERIVE_ALL = 255
 ABI_VERSION = 2

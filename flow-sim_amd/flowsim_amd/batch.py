@@ -42,14 +42,15 @@ def _dptr(a):
 
 class PreissmannBatch:
     def __init__(self, n_reaches: int, n_nodes: int, max_levels: int, dtype: str = "f64",
-                 section_mode: str = "rect_uniform", device: int = 0, history: bool = False, trace: bool = False):
+                 section_mode: str = "rect_uniform", device: int = 0, history: bool = False, trace: bool = False,
+                 monitor: bool = False):
         self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
         self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
         self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "trap_uniform": A.SEC_TRAP_UNIFORM,
                      "table": A.SEC_TABLE, "irregular": A.SEC_IRREGULAR}[section_mode]
         self._lib = A.lib()
         desc = A.BatchDesc(self.B, self.N, self.dtype, self.mode, device, self.L,
-                           (A.FLAG_HISTORY if history else 0) | (A.FLAG_TRACE if trace else 0), 0)
+                           (A.FLAG_HISTORY if history else 0) | (A.FLAG_TRACE if trace else 0) | (A.FLAG_MONITOR if monitor else 0), 0)
         self._h = self._lib.fs_batch_create(C.byref(desc))
         if not self._h:
             raise A.FlowsimError(A.last_error())

@@ -65,6 +65,12 @@ class PreissmannSolver(Solver):
         return A_reg / (A_reg + A_min)
 
     def run(self, tolerance=1e-4, verbose=3, max_iter=100, diagnos=False, dtype="f64") -> None:
+        """preissmann.py:101-163.  `diagnos`: in the reference it adds a NaN check and a SuperLU condition estimate per
+        iteration and raises ValueError("Jacobian is ill-conditioned (rcond too small)") below 1e-12 (:133-144) - on current
+        scipy that line itself fails (SuperLU objects have no `rcond`), SURVEY section 0.  Here the kernel watches the
+        conditioning of its own elimination for free (FS_ILL_CONDITIONED, include/flowsim_abi.h): with diagnos=True such a
+        run raises the reference's ValueError text, without it the run completes, `self.ill_conditioned` is set and a
+        RuntimeWarning says that the results may differ from the reference's beyond 1e-8."""
         ch = self.channel
         if self.regularization:
             self.area_at(k=0, i=0)                 # the reference's first residual evaluation: raises TypeError (Solver.area_at)
@@ -96,6 +102,9 @@ class PreissmannSolver(Solver):
             elif nt > 1:
                 b.step(nt - 1)
             status = int(b.status()[0])
+            self.ill_conditioned = status == A.ILL_CONDITIONED
+            if self.ill_conditioned:
+                status = A.OK                      # a warning: the run is complete
             its = b.iterations(0, max(nt, 2))[:nt, 0]
             h, Q = b.history_arrays(0, max(nt, 2))
             gh, gQ = b.guess()
@@ -120,6 +129,13 @@ class PreissmannSolver(Solver):
             raise ValueError("NaN in system assembly")
         self.time_level = nt - 1
         self.depth[:], self.flow[:] = h[:nt, 0], Q[:nt, 0]
+        if self.ill_conditioned:
+            if diagnos:
+                self.check_criticality()
+                raise ValueError("Jacobian is ill-conditioned (rcond too small)")          # preissmann.py:144
+            import warnings
+            warnings.warn("Preissmann systems of this run are ill-conditioned (supercritical flow over a long stretch?): results "
+                          "may differ from another solver's beyond 1e-8; run(diagnos=True) raises instead", RuntimeWarning)
         st = ch.downstream_boundary.lumped_storage
         if st is not None and A.DOWNSTREAM not in host_sides:     # (a host-evaluated storage keeps the list itself)
             st.stage_hydrograph = [[k * self.time_step, float(stages[k])] for k in range(1, nt)]
@@ -159,7 +175,7 @@ class PreissmannSolver(Solver):
                     b.set_host_rows(side, rows[side][0], rows[side][1], res[side])
                 if b.iterate() == 0:
                     break
-            if int(b.status()[0]) != A.OK:
+            if int(b.status()[0]) not in (A.OK, A.ILL_CONDITIONED):
                 return
 
     def check_criticality(self) -> None:

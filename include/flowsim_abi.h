@@ -34,7 +34,9 @@ extern "C" {
 
 typedef struct fs_batch fs_batch;
 
-/* arithmetic type of the path (reference: float64 everywhere, solver.py:43-44) */
+/* arithmetic type of the path (reference: float64 everywhere, solver.py:43-44).  FS_F32 is a throughput mode for large
+ * ensembles of short reaches (BASELINE configs[4]): it holds 5e-4 of the fp64 answer at tolerance 1e-3, cannot resolve
+ * ||R|| below ~6e-8 |Q| sqrt(2N) (4 096-node reaches need a tolerance of ~2e-2) and carries no 1e-8 parity claim. */
 enum { FS_F64 = 0, FS_F32 = 1 };
 
 /* How node geometry reaches the kernel.
@@ -110,13 +112,25 @@ enum {
 enum { FS_UPSTREAM = 0, FS_DOWNSTREAM = 1 };
 
 /* per-reach status after stepping (preissmann.py:124-126 raises ValueError; :135-137 NaN check) */
-enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3 };
+enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3,
+       /* A warning, not a failure (the reach keeps stepping and the status sticks): the linear systems of this reach are
+        * ill-conditioned - in practice supercritical flow (v > c) over a long stretch, where one boundary condition per end
+        * is not what the flow takes.  The on-chip elimination does not pivot; it watches how strongly the first unknown of any
+        * segment of rows depends on the last one (a product of super-diagonal / pivot ratios that decays for subcritical
+        * flow) and raises this status when that exceeds 2^10: results may then differ from another solver's (the reference's
+        * SuperLU included) by more than the 1e-8 this library otherwise keeps.  The reference's counterpart is the
+        * `diagnos` check of run(), ValueError("Jacobian is ill-conditioned (rcond too small)"), preissmann.py:139-144, and
+        * the Froude diagnosis of check_criticality (:179-198).  Raised by the kernels compiled with diagnostics: every batch
+        * with FS_FLAG_HISTORY, FS_FLAG_TRACE or FS_FLAG_MONITOR, and every batch no specialised kernel exists for. */
+       FS_ILL_CONDITIONED = 4 };
 
 enum {
   FS_FLAG_HISTORY = 1,  /* keep depth/flow[level][B][N] on the device (solver.py:43-44); large batches that only need the
                            boundary hydrographs leave it (and FS_FLAG_TRACE) off: no [levels][B][N] arrays in HBM and
                            step kernels compiled without those stores */
-  FS_FLAG_TRACE = 2     /* keep ||R|| of every Newton iteration (what run(verbose=3) prints, preissmann.py:149-152) */
+  FS_FLAG_TRACE = 2,    /* keep ||R|| of every Newton iteration (what run(verbose=3) prints, preissmann.py:149-152) */
+  FS_FLAG_MONITOR = 4   /* run the conditioning monitor (FS_ILL_CONDITIONED) also on a batch that keeps neither history nor trace:
+                           selects the kernels compiled with diagnostics (about 1 % slower on the 4 096-node benchmark shape) */
 };
 #define FS_TRACE_CAP 64 /* iterations per level kept by FS_FLAG_TRACE */
 
@@ -195,7 +209,10 @@ int fs_batch_get_boundary_iterate(fs_batch *b, double *out);
  * everything a run needs to continue bit-exactly from time level `level`: depth/flow[level] (h, Q: what
  * fs_batch_get_state returned), the Newton start vector of level+1 (h_guess, Q_guess: fs_batch_get_guess; after the
  * first level it differs from the state) and, behind a storage boundary, the reservoir stage of `level`
- * (storage_stage[B]: fs_batch_get_storage_stage; NULL otherwise).  All [B][N] float64. */
+ * (storage_stage[B]: fs_batch_get_storage_stage; required behind a storage boundary when level > 0, NULL otherwise).  All
+ * [B][N] float64.  A batch that keeps a history (FS_FLAG_HISTORY) holds, after a restart, the rows from `level` on:
+ * fs_batch_get_history / fs_batch_derive refuse ranges that begin before it, and the amplitude fields of fs_batch_derive
+ * (solver.py:96-97: depth - depth[0]) then refer to the restart state.  The per-reach status starts from FS_OK again. */
 int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *Q, const double *h_guess,
                      const double *Q_guess, const double *storage_stage);
 
@@ -252,7 +269,7 @@ int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_
                          int32_t *lds_bytes, int32_t *vgprs);
 /* The dispatch table of the step kernel (what fs_batch_step chooses from): fs_kernel_table_size() entries,
  * entry i described by out[8] = dtype, section_mode, cells per lane M, waves per reach W, full (1: only
- * N-1 in {64*W*M-1, 64*W*M}), boundary class (-1 any kind, 0 any but FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW,
+ * N == 64*W*M: the downstream boundary row takes the last row of the lane grid), boundary class (-1 any kind, 0 any but FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW,
  * 1 closed-form rectangular rows, 2+k flow hydrograph upstream and kind k downstream), diag (0: compiled
  * without history / trace stores), one reserved slot (0).  The environment
  * variable FS_KERNEL_INDEX=i makes fs_batch_step use entry i or fail if it does not fit the batch (tests:

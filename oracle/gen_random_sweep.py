@@ -148,6 +148,50 @@ def draw_bend_recipe(rng):
     return r
 
 
+def draw_near_critical_recipe(rng):
+    """a steep, smooth prismatic or compound reach whose base flow runs near or beyond critical depth (Froude number of the
+    normal flow 0.9 ... 1.5), long enough (65 ... 513 nodes) for the supercritical regime to show in the conditioning of the
+    Newton systems.  The scheme and the reference are built for subcritical rivers (the GVF set-up refuses such a profile,
+    channel.py:327-332, so the initial condition is the steady state); the reference still runs these, and its answers pin
+    what the kernel - whose elimination does not pivot - returns there, or that it raises FS_ILL_CONDITIONED."""
+    N = int(rng.choice([65, 129, 200, 257, 400, 513]))
+    dx = float(int(np.exp(rng.uniform(np.log(40.0), np.log(1500.0)))))
+    dt = int(np.exp(rng.uniform(np.log(30.0), np.log(800.0))))
+    n_steps = int(rng.integers(3, 6))
+    theta = float(rng.uniform(0.55, 1.0))
+    L = (N - 1) * dx
+    family = ("rect", "trap", "compound")[rng.integers(0, 3)]
+    b0 = float(np.exp(rng.uniform(np.log(5.0), np.log(450.0))))
+    n_main = float(rng.uniform(0.012, 0.02))
+    q = float(np.exp(rng.uniform(np.log(0.5), np.log(6.0))))
+    Fr = float(rng.uniform(0.9, 1.5))
+    h = (q * q / (9.80665 * Fr * Fr)) ** (1.0 / 3.0)                  # wide-channel estimates: Fr^2 = q^2 / (g h^3), q = h^(5/3) sqrt(S0) / n
+    S0 = float((q * n_main / h ** (5.0 / 3.0)) ** 2)
+    Qb = q * b0
+    sections = []
+    for c in (0.0, L):
+        z = S0 * (L - c)
+        kw = dict(z_bed=z, b_main=b0, m_main=0.0, n_main=n_main, bed_slope=S0)
+        if family != "rect":
+            kw["m_main"] = float(rng.uniform(0.5, 2.5)) if c == 0.0 else sections[0]["m_main"]
+        if family == "compound":
+            if c == 0.0:
+                kw.update(z_bank=z + float(rng.uniform(1.2, 2.5)) * h, b_fp_left=b0 * float(rng.uniform(0.5, 3)),
+                          b_fp_right=b0 * float(rng.uniform(0.5, 3)), m_fp=float(rng.uniform(2, 6)),
+                          n_left=n_main * float(rng.uniform(1.5, 3)), n_right=n_main * float(rng.uniform(1.5, 3)))
+            else:
+                kw.update({k: v for k, v in sections[0].items() if k in ("b_fp_left", "b_fp_right", "m_fp", "n_left", "n_right")})
+                kw["z_bank"] = z + (sections[0]["z_bank"] - sections[0]["z_bed"])
+        sections.append(kw)
+    amp = float(np.exp(rng.uniform(np.log(0.1), np.log(1.5))))
+    us_kind = ("flow_hydrograph", "flow_hydrograph", "stage_hydrograph", "fixed_depth")[rng.integers(0, 4)]
+    ds_kind = ("normal_depth", "normal_depth", "power", "polynomial", "fixed_depth")[rng.integers(0, 5)]
+    wave = dict(rise=float(rng.uniform(2, 5)) * dt, fall=float(rng.uniform(6, 12)) * dt)
+    return dict(N=N, dx=dx, dt=dt, n_steps=n_steps, theta=theta, L=L, S0=S0, family=family, b0=b0, Qb=Qb, chain=[0.0, L],
+                sections=sections, amp=amp, us_kind=us_kind, ds_kind=ds_kind, ic="steady-state", wave=wave,
+                rc_exponent=float(rng.uniform(1.3, 2.0)), froude_target=Fr)
+
+
 def make_section(kw):
     from src.hydromodel.cross_section import IrregularSection, TrapezoidalSection
     if "x" not in kw:
@@ -188,6 +232,10 @@ def build_from_recipe(r):
     if r["us_kind"] == "flow_hydrograph":
         hyd = Hydrograph(flood_wave(Qb, r["amp"] * Qb, r["wave"]["rise"], r["wave"]["fall"]))
         us = Boundary(condition='flow_hydrograph', bed_level=z_us, chainage=0, initial_depth=h_us, hydrograph=hyd)   # (the linear IC reads it)
+    elif r["us_kind"] == "fixed_depth":       # a reservoir level held upstream (nothing to sample: the stored target is constant)
+        hyd = Hydrograph(table=np.array([[0.0, float(h_us)], [1e9, float(h_us)]]))
+        us = Boundary(condition='fixed_depth', bed_level=z_us, chainage=0, initial_depth=h_us * (1.0 + 0.1 * min(r["amp"], 1.0)))   # the level steps up at t = 0
+        extra["us_initial_depth"] = float(us.initial_depth)
     else:
         t_end = r["n_steps"] * dt
         tab = np.array([[0.0, z_us + h_us], [0.3 * t_end, z_us + h_us * (1 + 0.25 * min(r["amp"], 1.0))],
@@ -248,6 +296,10 @@ def main():
     ap.add_argument("--polyline", type=int, default=12)
     ap.add_argument("--storage", type=int, default=12)
     ap.add_argument("--bends", type=int, default=8)
+    ap.add_argument("--near-critical", type=int, default=0,
+                    help="this many near-critical / supercritical reaches INSTEAD of the sweep (tests/golden/near_critical.npz): "
+                         "for each case the fixture also keeps the 1-norm condition number of the reference's Jacobian at the first "
+                         "Newton iteration of every level; half of the cases are the worst-conditioned of the draws")
     ap.add_argument("--seed", type=int, default=20260301)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "random_sweep.npz"),
                     help="a soak run writes elsewhere (e.g. gpurun_out/sweep_soak.npz, FS_SWEEP_FIXTURE for the tests)")
@@ -260,6 +312,8 @@ def main():
     sys.path.insert(0, "/root/reference")
     from gen_golden import base_meta, run_and_capture, sample_targets
 
+    if a.near_critical:
+        return near_critical(a, out_path, base_meta, run_and_capture, sample_targets)
     rng = np.random.default_rng(a.seed)
     rng_poly = np.random.default_rng(a.seed + 1)          # a stream of its own: the trapezoid-family cases stay what they were
     arrays, metas, tried, t0 = {}, [], 0, time.time()
@@ -297,6 +351,67 @@ def main():
     path = out_path
     np.savez_compressed(path, meta=np.array(json.dumps(meta)), **arrays)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB): {len(metas)} cases of {tried} draws in {time.time() - t0:.0f} s")
+
+
+def near_critical(a, out_path, base_meta, run_and_capture, sample_targets):
+    """draws 4 x the wanted number of near-critical reaches, runs the reference on each and keeps the worst-conditioned
+    half of the wanted number plus an even spread of the rest"""
+    import scipy.sparse.linalg as spla
+    if out_path.endswith("random_sweep.npz"):
+        out_path = os.path.join(os.path.dirname(out_path), "near_critical.npz")
+    rng = np.random.default_rng(a.seed + 7)
+    pool, tried, t0 = [], 0, time.time()
+    while len(pool) < 4 * a.near_critical and tried < 12 * a.near_critical:
+        tried += 1
+        recipe = draw_near_critical_recipe(rng)
+        try:
+            sol, hyd, extra = build_from_recipe(recipe)
+            conds, seen = [], set()
+            orig = spla.spsolve
+
+            def spy(J, b, *aa, _sol=sol, **kk):      # condition number of the reference's own matrix, first iteration of a level
+                if _sol.time_level not in seen:
+                    seen.add(_sol.time_level)
+                    conds.append(float(np.linalg.cond(J.toarray(), 1)))
+                return orig(J, b, *aa, **kk)
+            spla.spsolve = spy
+            try:
+                out, wall = run_and_capture(sol, 1e-6, slim=True)
+            finally:
+                spla.spsolve = orig
+        except (ValueError, RuntimeError, ZeroDivisionError, FloatingPointError) as e:
+            print(f"  draw {tried}: reference raised {type(e).__name__}: {str(e)[:70]}")
+            continue
+        if not (np.all(np.isfinite(out["depth"])) and np.min(out["depth"]) > 0):
+            continue
+        h = out["depth"]; Q = out["flow"]
+        xs = sol.channel.xs_at_node
+        fr = max(abs(Q[k, i]) / xs[i].area(xs[i].z_min + h[k, i]) / (9.80665 * xs[i].area(xs[i].z_min + h[k, i]) / xs[i].top_width(xs[i].z_min + h[k, i])) ** 0.5
+                 for k in range(h.shape[0]) for i in range(0, h.shape[1], max(1, h.shape[1] // 16)))
+        out["us_target"] = sample_targets(hyd, sol.number_of_time_levels, sol.time_step)
+        for k in ("R0", "norm_level", "norm_value", "final_unknowns"):
+            out.pop(k, None)
+        out["cond1"] = np.array(conds)
+        m = base_meta(sol, 1e-6, wall, **extra)
+        m.update(family=recipe["family"], n_sections=2, us_kind=recipe["us_kind"], ds_kind=recipe["ds_kind"], ic=recipe["ic"],
+                 Qb=recipe["Qb"], amp=recipe["amp"], bends=False, recipe=recipe, froude_max=float(fr), cond1_max=float(max(conds)))
+        pool.append((out, m))
+        print(f"  draw {tried}: N={m['N']:4d} {m['family']:8s} {m['us_kind'][:5]} -> {m['ds_kind']:12s} Fr<={fr:.2f} cond1 {max(conds):.1e} "
+              f"its={out['iters'][1:].tolist()}")
+    pool.sort(key=lambda om: -om[1]["cond1_max"])
+    half = a.near_critical // 2
+    rest = pool[half:]
+    keep = pool[:half] + [rest[int(i * len(rest) / (a.near_critical - half))] for i in range(a.near_critical - half)]
+    arrays, metas = {}, []
+    for i, (out, m) in enumerate(keep):
+        for k, v in out.items():
+            arrays[f"c{i:02d}_{k}"] = v
+        metas.append(m)
+    meta = dict(generator="oracle/gen_random_sweep.py --near-critical", reference="cve-mohd/flow-sim snapshot 2026-02-13, run in the build container",
+                seed=a.seed + 7, draws=tried, cases=metas)
+    np.savez_compressed(out_path, meta=np.array(json.dumps(meta)), **arrays)
+    print(f"wrote {out_path} ({os.path.getsize(out_path) / 1024:.0f} KiB): {len(metas)} cases of {tried} draws in {time.time() - t0:.0f} s; "
+          f"cond1 from {min(m['cond1_max'] for m in metas):.1e} to {max(m['cond1_max'] for m in metas):.1e}")
 
 
 if __name__ == "__main__":

@@ -83,7 +83,7 @@ def merge(X, Y):
     return Z, dict(A1=A1, A2=A2, A3=A3, rc=X["rc"], det=det, scale=np.abs(X["d2"] * Y["u2"]) + np.abs(X["d3"] * Y["u1"]))
 
 
-def solve(data, R, m, T=None, dtype=np.float64):
+def solve(data, R, m, T=None, dtype=np.float64, info=None):
     """Returns (delta[2N] with J delta = -R computed with the device's elimination order, smallest pivot relative to
     its terms)."""
     N = len(R) // 2
@@ -116,6 +116,9 @@ def solve(data, R, m, T=None, dtype=np.float64):
         d1, d2, d3, rd = al[:, j] * R1, newd2, de[:, j], rho + al[:, j] * R3
         u1, u3, ru = u1 - u3 * R1, -u3 * R2, ru - u3 * R3
     seg = dict(u1=u1, u2=u2, u3=u3, ru=ru, d1=d1, d2=d2, d3=d3, rd=rd, rc=rc[:, m - 1])
+    growth = np.abs(u3)                                      # the kernel's conditioning monitor: largest |u3| of any segment
+    aux = dict(d1d2=float(np.max(np.abs(d1 / d2))), A1=0.0, A2=0.0, R1=max(float(np.max(np.abs(r[0]))) for r in rec) if rec else 0.0,
+               R2=max(float(np.max(np.abs(r[1]))) for r in rec) if rec else 0.0, u1=float(np.max(np.abs(u1))))
     # 2. tree
     levels = []
     while len(seg["u1"]) > 1:
@@ -123,12 +126,17 @@ def solve(data, R, m, T=None, dtype=np.float64):
         Y = {k: v[1::2] for k, v in seg.items()}
         seg, el = merge(X, Y)
         levels.append(el)
+        growth = np.maximum(np.maximum(growth[0::2], growth[1::2]), np.abs(seg["u3"]))
+        aux["A1"] = max(aux["A1"], float(np.max(np.abs(el["A1"])))); aux["A2"] = max(aux["A2"], float(np.max(np.abs(el["A2"]))))
+        aux["d1d2"] = max(aux["d1d2"], float(np.max(np.abs(seg["d1"] / seg["d2"])))); aux["u1"] = max(aux["u1"], float(np.max(np.abs(seg["u1"]))))
         worst = min(worst, np.min(np.abs(el["det"]) / el["scale"]))
     S = {k: v[0] for k, v in seg.items()}
     # root: up  u1 p_0 + u2 m_0 + u3 m_last = ru ; down  d1 p_0 + d2 m_last = rd (nothing right of the last row) ; U row
     r = one / S["d2"]
     e1, e3 = S["u1"] - S["u3"] * S["d1"] * r, S["ru"] - S["u3"] * S["rd"] * r        # e1 p_0 + u2 m_0 = e3
     det = aU * S["u2"] - bU * e1
+    if info is not None:     # what the kernel's conditioning monitor sees (fs_device.hpp: close_root)
+        info.update(growth=float(growth[0]), aux=aux, root=dict(S), aU=aU, bU=bU, e1=e1, det=det, f=S["u3"] * r)
     worst = min(worst, abs(det) / (abs(aU * S["u2"]) + abs(bU * e1)))
     p0 = (rU * S["u2"] - bU * e3) / det
     mlast = (S["rd"] - S["d1"] * p0) * r

@@ -202,6 +202,59 @@ def test_restart_continues_bit_exactly():
                 assert np.array_equal(x, y)
 
 
+def test_restart_guards():
+    """what fs_batch_restart refuses or restricts: a storage boundary without the reservoir stage of the restart level (the
+    run would silently go on from stage 0), and - for a batch that keeps a history - ranges that begin before the restart
+    level (those rows were not restored; amplitudes then refer to the restart state)"""
+    from fixture_batch import batch_from_problems
+    from flowsim_amd._abi import FlowsimError
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "example.npz"))              # fixed depth behind a LumpedStorage
+    p = O.problem_from_fixture(fx, meta)
+    k, nt = 5, 12
+    with batch_from_problems([p], history=True) as a:
+        a.step(nt - 1)
+        want_h, want_Q = a.history_arrays(0, nt)
+        want = a.derive(k, nt - k)
+    with batch_from_problems([p], history=True) as b:
+        b.step(k)
+        snap = b.state() + b.guess()
+        stage = b.storage_stage()
+    with batch_from_problems([p], history=True) as c:
+        with pytest.raises(FlowsimError, match="reservoir stage"):
+            c.restart(k, *snap)                                                   # storage stage missing
+        c.restart(k, *snap, stage)
+        c.step(nt - 1 - k)
+        assert np.all(c.status() == 0)
+        h, Q = c.history_arrays(k, nt - k)
+        assert np.array_equal(h, want_h[k:]) and np.array_equal(Q, want_Q[k:])    # the continued history, bit for bit
+        with pytest.raises(FlowsimError, match="restarted at level"):
+            c.history_arrays(0, nt)
+        with pytest.raises(FlowsimError, match="restarted at level"):
+            c.derive(0, nt)
+        got = c.derive(k, nt - k)
+        for name in ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity"):
+            assert np.array_equal(got[name], want[name]), name
+        # amplitudes refer to the restart state (row 0 of the restarted batch), not to the initial condition
+        np.testing.assert_allclose(got["amplitude"], want_h[k:] - want_h[k][None], rtol=0, atol=1e-12)
+
+
+def test_a_new_state_closes_a_level_left_open_by_iterate():
+    """fs_batch_iterate leaves its level open until every reach has accepted it; both state setters start over"""
+    from fixture_batch import batch_from_problems
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "akbari.npz"))              # steady-state initial condition: one depth, one flow
+    p = O.problem_from_fixture(fx, meta)
+    with batch_from_problems([p], mode="table") as b:
+        assert b.iterate() == 1                                       # one Newton iteration of level 1: still open
+        with pytest.raises(Exception, match="fs_batch_iterate"):
+            b.step(1)
+        b.set_state_uniform(float(p.h0[0]), float(p.Q0[0]))
+        b.step(1)                                                     # accepted again
+        b.iterate()
+        b.set_state(p.h0[None], p.Q0[None])
+        b.step(2)
+        assert b.level == 2 and np.all(b.status() == 0)
+
+
 def test_calibration_rmse_curve_matches_the_reference():
     """cases/gerd_roseires/n_calibrate - the ten-member Manning-n study as ONE device batch - against
     the curve the reference's own loop produced (n_calibrate.py:55-67 over model.run; tests/golden/rmse_curve.npz;

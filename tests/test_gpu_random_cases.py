@@ -3,7 +3,14 @@
 numbers 0.3 ... 300), slopes 5e-5 ... 5e-3, widths 3 ... 600 m, Manning 0.012 ... 0.08, rectangles and trapezoids, every
 pair of closed-form boundary kinds, flood waves of 10 % ... 300 % of the base flow - against the C oracle (pivoted banded
 LU, the reference's algorithm).  fp64: 1e-8 relative on the whole history, identical Newton counts; the draw is part of
-the test (seeded), a draw the ORACLE cannot solve is skipped and counted."""
+the test (seeded), a draw the ORACLE cannot solve is skipped and counted.
+
+Supercritical draws are part of the sweep: there the Newton systems can be ill-conditioned (cond 1e13 ... 1e16: one boundary
+condition per end is not what such a flow takes) and any two solvers part by 1e-6 ... 1e-2 - the reference and its own
+restatements included (tests/test_near_critical.py pins that against the reference itself).  The rule for every draw is
+therefore: 1e-8 with identical Newton counts, OR the kernel says so - status FS_ILL_CONDITIONED, raised by the conditioning
+monitor of its elimination (include/flowsim_abi.h).  A last test keeps the monitor honest: it may flag only a small share
+of the draws, and none of the clearly subcritical ones."""
 import os
 
 import numpy as np
@@ -148,6 +155,9 @@ def random_table_problem(seed):
 
 _solved = []
 _solved_table = []
+_flagged = []          # (sweep, seed, Froude number or None, error) of every draw the conditioning monitor flagged
+_unflagged_froude = []
+ILL = 4                # FS_ILL_CONDITIONED
 N_TABLE = int(os.environ.get("FS_SWEEP_TABLE", 128))
 
 
@@ -163,13 +173,17 @@ def test_random_compound_channel_against_the_oracle(seed):
     _solved_table.append(True)
     with batch_from_problems([p], mode="table", history=True) as b:
         b.step(p.nt - 1)
-        assert np.all(b.status() == 0), (b.status(), info)
+        st = int(b.status()[0])
+        assert st in (0, ILL), (st, info)
         h, Q = b.history_arrays(0, p.nt)
         its = b.iterations(0, p.nt)[:, 0]
     d, f = ref["depth"], ref["flow"]
     eh, eq = rel_err(h[:, 0], d, 1e-3 * info["hn"]), rel_err(Q[:, 0], f, 1e-3 * info["Qb"])
-    assert eh <= TOL and eq <= TOL, (eh, eq, info)
-    assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
+    if st == ILL:
+        _flagged.append(("table", seed, None, max(eh, eq)))
+    else:
+        assert eh <= TOL and eq <= TOL, (eh, eq, info)
+        assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
     over = np.any(d > p.geo["h_bf"][None, :]) and np.any(d < p.geo["h_bf"][None, :])
     info["both_sides_of_bankfull"] = bool(over)
 
@@ -179,13 +193,6 @@ def test_random_reach_against_the_oracle(seed):
     from fixture_batch import batch_from_problems
     from oracle import c_oracle as CO
     p, info = random_problem(seed)
-    if info["froude"] >= 0.9:
-        # supercritical base flow: one boundary condition at each end is not what such a flow takes, the Newton systems are
-        # ill-conditioned (cond up to 3e15) and the time stepping amplifies rounding differences tenfold per level: the two CPU
-        # oracles themselves (pivoted LU in C, SuperLU in numpy) part by 1e-4 there (a soak run of 8 000 draws found 4 such
-        # cases); the reference's own set-up refuses supercritical profiles (channel.py:329)
-        _solved.append(True)
-        pytest.skip(f"supercritical draw (Fr = {info['froude']:.2f}): outside the scheme's domain")
     ref = CO.run(p)
     if ref["status"] != 0 or not np.all(np.isfinite(ref["depth"])) or np.min(ref["depth"]) <= 1e-3 * info["hn"]:
         _solved.append(False)
@@ -194,13 +201,28 @@ def test_random_reach_against_the_oracle(seed):
     mode = "rect_uniform" if (not info["trapezoid"] and info["ds"] != "blend") else ("trap_uniform" if info["trapezoid"] and seed % 2 else "table")
     with batch_from_problems([p], mode=mode, history=True) as b:
         b.step(p.nt - 1)
-        assert np.all(b.status() == 0), (b.status(), info)
+        st = int(b.status()[0])
+        assert st in (0, ILL), (st, info)
         h, Q = b.history_arrays(0, p.nt)
         its = b.iterations(0, p.nt)[:, 0]
     d, f = ref["depth"], ref["flow"]
     eh, eq = rel_err(h[:, 0], d, 1e-3 * info["hn"]), rel_err(Q[:, 0], f, 1e-3 * info["Qb"])
+    if st == ILL:
+        # the kernel itself says that this reach is beyond what its unpivoted elimination (or any solver, at 1e-8) stands for
+        _flagged.append(("prismatic", seed, info["froude"], max(eh, eq)))
+        return
+    _unflagged_froude.append(info["froude"])
     assert eh <= TOL and eq <= TOL, (eh, eq, info)
     assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
+
+
+def test_the_monitor_flags_few_draws_and_no_subcritical_prismatic_one():
+    if len(_solved) < N_CASES or len(_solved_table) < N_TABLE:
+        pytest.skip("runs after the sweeps")
+    prism = [f for f in _flagged if f[0] == "prismatic"]
+    assert all(fr >= 0.85 for _, _, fr, _ in prism), prism            # a flag on a prismatic reach means supercritical (or nearly) flow
+    assert len(prism) <= 0.02 * N_CASES + 2 and len(_flagged) - len(prism) <= 0.03 * N_TABLE + 2, _flagged
+    assert sum(fr >= 0.9 for fr in _unflagged_froude) >= 1 or N_CASES < 300        # supercritical draws that pass at 1e-8 unflagged exist too
 
 
 def tidal_problem(seed):

@@ -1,8 +1,8 @@
 #!/bin/bash
-# rocprofv3 passes for profiles/round2:  tools/profile.sh TAG <bench.py arguments ...>
+# rocprofv3 passes for profiles/round3:  tools/profile.sh TAG <bench.py arguments ...>
 #   kernel trace + stats, then the HBM traffic counters in separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
 #   do not fit one pass; counters are never combined with system traces), the issue counters and the flop counters.
-# Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round2/.
+# Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round3/.
 set -e
 TAG=$1; shift
 ROOT=$(pwd)

@@ -16,7 +16,10 @@ import argparse, csv, glob, json, os, shutil, sys
 ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--kernel", default="preissmann")
-ap.add_argument("--round", default="round2")
+ap.add_argument("--round", default="round3")
+ap.add_argument("--second", default=None,
+                help="tag of a second run of the same workload with another number of levels in its launch: the two together give the "
+                     "part of the traffic that does not depend on the levels (state in, state out) and the part per level")
 a = ap.parse_args()
 P, D = f"gpurun_out/prof/{a.tag}", f"profiles/{a.round}"
 os.makedirs(D, exist_ok=True)
@@ -61,6 +64,26 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                algorithmic_bytes_per_reach_timestep=4 * N * real + 40,
                traffic_note="rocprofv3 FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B; the kernel's known reads - "
                             "hk, Qk, hg, Qg once per launch - calibrate it) + WRITE_SIZE, separate passes, per reach-timestep")
+if a.second and "FETCH_SIZE" in vals:
+    P2 = f"gpurun_out/prof/{a.second}"
+    b2 = json.loads(open(f"{P2}/bench_trace.json").read().strip().split("\n")[-1])
+    v2 = {}
+    for name in ("pmc_fetch", "pmc_write"):
+        rows = list(csv.reader(open(newest(f"{P2}/{name}/**/*_counter_collection.csv"))))
+        h = rows[0]
+        ci, cv, di, kn = h.index("Counter_Name"), h.index("Counter_Value"), h.index("Dispatch_Id"), h.index("Kernel_Name")
+        keep = [r for r in rows[1:] if a.kernel in r[kn]]
+        last = max(int(r[di]) for r in keep)
+        v2.update({r[ci]: float(r[cv]) for r in keep if int(r[di]) == last})
+    K2 = b2["steps"]
+    assert b2["config"]["reaches_per_gpu"] == B and b2["config"]["nodes"] == N and K2 != K
+    t1 = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 / B            # per reach, launch of K levels
+    t2 = (2 * v2["FETCH_SIZE"] + v2["WRITE_SIZE"]) * 1024 / B                # per reach, launch of K2 levels
+    per_level = (t1 - t2) / (K - K2)
+    out.update(hbm_bytes_per_reach_fixed=t1 - per_level * K, hbm_bytes_per_reach_per_level=per_level,
+               second_profile=dict(tag=a.second, levels_in_launch=K2, hbm_bytes_per_reach=t2),
+               traffic_note="rocprofv3 FETCH_SIZE x 2 (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, separate passes, of the "
+                            f"timed launch at {K} and at {K2} levels: bytes per reach = fixed (state in, state out) + per_level x levels")
 w = vals.get("SQ_WAVES")
 if w and "SQ_INSTS_VALU" in vals:
     sfx = "F64" if real == 8 else "F32"
@@ -68,8 +91,7 @@ if w and "SQ_INSTS_VALU" in vals:
                + vals[f"SQ_INSTS_VALU_TRANS_{sfx}"])
     out.update(flops_per_launch=fl, flops_per_reach_iteration=fl / (B * K * its),
                valu_instructions_per_wave_iteration=vals["SQ_INSTS_VALU"] / w / (K * its),
-               arithmetic_share_of_valu=fl / 64 / (vals["SQ_INSTS_VALU"] + vals[f"SQ_INSTS_VALU_FMA_{sfx}"]) if False else
-               (vals[f"SQ_INSTS_VALU_FMA_{sfx}"] + vals[f"SQ_INSTS_VALU_MUL_{sfx}"] + vals[f"SQ_INSTS_VALU_ADD_{sfx}"]
+               arithmetic_share_of_valu=(vals[f"SQ_INSTS_VALU_FMA_{sfx}"] + vals[f"SQ_INSTS_VALU_MUL_{sfx}"] + vals[f"SQ_INSTS_VALU_ADD_{sfx}"]
                 + vals[f"SQ_INSTS_VALU_TRANS_{sfx}"]) / vals["SQ_INSTS_VALU"])
 if "SQ_ACTIVE_INST_VALU" in vals:
     out.update(valu_active_per_wave_cycle=vals["SQ_ACTIVE_INST_VALU"] / vals["SQ_WAVE_CYCLES"],
