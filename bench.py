@@ -182,6 +182,9 @@ def main():
                     help="c4 only: override the case's spatial step (m); the node count follows (default 1000 m: 121 nodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--dump-hydrographs", default=None,
+                    help="rank 0 saves the gathered boundary hydrographs of the timed levels [K, 4, all reaches] to this .npy "
+                         "(tests compare a multi-rank run with a one-process run of the same global reaches, bit for bit)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (multi-rank control flow on a one-GPU box, gloo)")
     args = ap.parse_args()
@@ -345,6 +348,8 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     kern_ms = batch.last_step_ms()
+    if args.dump_hydrographs and rank == 0:
+        np.save(args.dump_hydrographs, gathered.cpu().numpy())
 
     st = batch.status()
     its = batch.iterations(Wm + 1, K)

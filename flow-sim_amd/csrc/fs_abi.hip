@@ -16,6 +16,16 @@
 
 #include "fs_entries.hpp"
 
+// ROCTx ranges around the phases a system trace should show (rocprofv3 --marker-trace): uploads, downloads, the step launch,
+// the post-processing launch.  Without a tool attached a push / pop is a few nanoseconds.
+#include <rocprofiler-sdk-roctx/roctx.h>
+namespace {
+struct TraceRange {
+  explicit TraceRange(const char *name) { roctxRangePushA(name); }
+  ~TraceRange() { roctxRangePop(); }
+};
+}  // namespace
+
 #ifndef FS_MINIMAL
 // the full library: the kernels are instantiated in the fs_part_*.hip translation units
 FS_LIST_RECT(FS_DECLARE, double, FS_F64) FS_LIST_RECT(FS_DECLARE, float, FS_F32)
@@ -187,6 +197,7 @@ struct fs_batch {
 namespace {
 
 int upload(fs_batch *b, void **dst, const double *src, size_t n) {
+  TraceRange range_("flowsim:upload");
   if (!*dst) HIP_TRY(hipMalloc(dst, n * b->esz));
   if (b->d.dtype == FS_F64) {
     HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -201,6 +212,7 @@ int upload(fs_batch *b, void **dst, const double *src, size_t n) {
 }
 
 int download(fs_batch *b, double *dst, const void *src, size_t off_elems, size_t n) {
+  TraceRange range_("flowsim:download");
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (b->d.dtype == FS_F64) {
     HIP_TRY(hipMemcpy(dst, (const char *)src + off_elems * 8, n * 8, hipMemcpyDeviceToHost));
@@ -265,6 +277,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
 
 // picks the instantiation for the batch as it is now (the boundary kinds are known) and launches it on the handle's stream
 int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
+  TraceRange range_(iter_budget > 0 ? "flowsim:iterate" : "flowsim:step");
   std::string why;
   const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
                                (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE | FS_FLAG_MONITOR)) != 0, &why, iter_budget > 0);
@@ -672,6 +685,7 @@ int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *
 int fs_batch_sync(fs_batch *b) {
   if (!b) return fail("null handle");
   FS_ON_DEVICE(b);
+  TraceRange range_("flowsim:sync");
   HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
@@ -761,6 +775,7 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
     return fail("fs_batch_derive: this batch was restarted at level " + std::to_string(b->restart_level) +
                 "; the history before it was not restored (row 0 holds the restart state, which amplitudes then refer to)");
   FS_ON_DEVICE(b);
+  TraceRange range_("flowsim:derive");
   const size_t BN = (size_t)b->d.n_reaches * b->d.n_nodes;
   void *dev[8] = {nullptr};
   for (int f = 0; f < 8; ++f) {

@@ -12,7 +12,8 @@ import numpy as np
 from . import preissmann_oracle as O
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "liboracle_c.so")
+_SAN = os.environ.get("FS_ORACLE_SAN") == "1"          # the ASan + UBSan build (make SAN=1; tests/test_sanitizers.py)
+_SO = os.path.join(_HERE, "_build", "liboracle_c_san.so" if _SAN else "liboracle_c.so")
 _D = C.POINTER(C.c_double)
 _KIND = {"flow_hydrograph": 0, "stage_hydrograph": 1, "normal_depth": 3}
 
@@ -34,7 +35,7 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_SO):
-            subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+            subprocess.run(["make", "-C", _HERE] + (["SAN=1"] if _SAN else []), check=True, capture_output=True)
         _lib = C.CDLL(_SO)
         _lib.fso_run.restype = C.c_int
         _lib.fso_run.argtypes = [C.POINTER(_Problem), _D, _D, C.POINTER(C.c_int), _D]

@@ -106,8 +106,12 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
     u1, u2, u3, ru = np.zeros(T, dtype), np.ones(T, dtype), -np.ones(T, dtype), np.zeros(T, dtype)
     rec = []
     worst = np.inf
+    cu = np.ones(T, dtype)         # largest |d ru / d rhs_j| over the lane's rows (sensitivity of the up row's right-hand side)
+    cd = np.ones(T, dtype)         # the same for the down row
     for j in range(1, m):
         r = one / d2
+        cu = np.maximum(cu, np.abs(u3 * r) * cd)
+        cd = np.maximum(1.0, np.abs(al[:, j] * r) * cd)
         R1, R2, R3 = d1 * r, d3 * r, rd * r                   # m_{j-1} = R3 - R1 p_a - R2 m_j
         rec.append((R1, R2, R3))
         rho = rho0[:, j] - al[:, j] * rc[:, j - 1]
@@ -116,6 +120,7 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
         d1, d2, d3, rd = al[:, j] * R1, newd2, de[:, j], rho + al[:, j] * R3
         u1, u3, ru = u1 - u3 * R1, -u3 * R2, ru - u3 * R3
     seg = dict(u1=u1, u2=u2, u3=u3, ru=ru, d1=d1, d2=d2, d3=d3, rd=rd, rc=rc[:, m - 1])
+    sens = [[cu.copy(), cd.copy()], [np.ones(T, dtype), np.ones(T, dtype)]]      # variant 0: exact in-lane start; variant 1: lanes start at 1
     growth = np.abs(u3)                                      # the kernel's conditioning monitor: largest |u3| of any segment
     aux = dict(d1d2=float(np.max(np.abs(d1 / d2))), A1=0.0, A2=0.0, R1=max(float(np.max(np.abs(r[0]))) for r in rec) if rec else 0.0,
                R2=max(float(np.max(np.abs(r[1]))) for r in rec) if rec else 0.0, u1=float(np.max(np.abs(u1))))
@@ -126,6 +131,12 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
         Y = {k: v[1::2] for k, v in seg.items()}
         seg, el = merge(X, Y)
         levels.append(el)
+        rr = 1.0 / el["det"]
+        for v in range(2):
+            cuX, cuY, cdX, cdY = sens[v][0][0::2], sens[v][0][1::2], sens[v][1][0::2], sens[v][1][1::2]
+            g2a = np.abs(X["d3"] * rr)
+            sens[v] = [np.maximum(np.maximum(cuX, np.abs(X["u3"] * rr) * cdX), np.abs(X["u3"]) * g2a * cuY),
+                       np.maximum(np.maximum(cdY, np.abs(Y["d1"] * rr) * cdX), np.abs(Y["d1"]) * g2a * cuY)]
         growth = np.maximum(np.maximum(growth[0::2], growth[1::2]), np.abs(seg["u3"]))
         aux["A1"] = max(aux["A1"], float(np.max(np.abs(el["A1"])))); aux["A2"] = max(aux["A2"], float(np.max(np.abs(el["A2"]))))
         aux["d1d2"] = max(aux["d1d2"], float(np.max(np.abs(seg["d1"] / seg["d2"])))); aux["u1"] = max(aux["u1"], float(np.max(np.abs(seg["u1"]))))
@@ -136,7 +147,9 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
     e1, e3 = S["u1"] - S["u3"] * S["d1"] * r, S["ru"] - S["u3"] * S["rd"] * r        # e1 p_0 + u2 m_0 = e3
     det = aU * S["u2"] - bU * e1
     if info is not None:     # what the kernel's conditioning monitor sees (fs_device.hpp: close_root)
-        info.update(growth=float(growth[0]), aux=aux, root=dict(S), aU=aU, bU=bU, e1=e1, det=det, f=S["u3"] * r)
+        sp = [abs(1.0 / det) * max(1.0, abs(bU) * max(c[0][0], abs(S["u3"] * r) * c[1][0])) for c in sens]       # of p_0
+        sl = [abs(r) * max(c[1][0], abs(S["d1"]) * q) for c, q in zip(sens, sp)]                                   # of m_last
+        info.update(growth=float(growth[0]), sens=[float(max(a_, b_)) for a_, b_ in zip(sp, sl)], aux=aux, root=dict(S), aU=aU, bU=bU, e1=e1, det=det, f=S["u3"] * r)
     worst = min(worst, abs(det) / (abs(aU * S["u2"]) + abs(bU * e1)))
     p0 = (rU * S["u2"] - bU * e3) / det
     mlast = (S["rd"] - S["d1"] * p0) * r
