@@ -180,6 +180,9 @@ def main():
                          "128 nodes)")
     ap.add_argument("--spatial-step", type=float, default=None,
                     help="c4 only: override the case's spatial step (m); the node count follows (default 1000 m: 121 nodes)")
+    ap.add_argument("--per-reach-geometry", action="store_true",
+                    help="c4 only: every member gets its own copy of the node table (fs_batch_set_geometry_table_per_reach), as a "
+                         "geometry Monte-Carlo would; the shared-table run is the default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--dump-hydrographs", default=None,
@@ -247,7 +250,11 @@ def main():
         theta, dt, dx, tol = solver.theta, float(solver.time_step), solver.spatial_step, 1e-6
         batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="table", device=local)
         batch.set_scheme(theta, dt, dx, tol, 100)
-        batch.set_geometry_table(ch.node_geometry, n_main_override=n_members)
+        if args.per_reach_geometry:
+            batch.set_geometry_table({k: np.broadcast_to(np.asarray(ch.node_geometry[k], dtype=np.float64), (B, N)) for k in A.GEO_ROWS},
+                                     n_main_override=n_members)
+        else:
+            batch.set_geometry_table(ch.node_geometry, n_main_override=n_members)
         batch.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, levels, dt))
         batch.set_boundary(A.DOWNSTREAM, boundary_to_spec(ch.downstream_boundary, levels, dt))
         ic = gvf_profiles(ch, n_members)

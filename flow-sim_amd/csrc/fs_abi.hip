@@ -118,7 +118,11 @@ const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRA
 // choice for experiments and tests.
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 
-bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, bool need_diag, bool need_any) {
+// hetero: bit 0 = per-reach node counts (ragged kernels only), bit 1 = per-reach scheme or boundary kinds (kernels that read
+// them: boundary classes 0 and -1)
+bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, bool need_diag, bool need_any, int hetero = 0) {
+  if ((hetero & 1) && e.full) return false;
+  if ((hetero & 2) && e.bck > 0) return false;
   const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
   if (e.dtype != dtype || e.sec != sec) return false;
@@ -135,10 +139,10 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
 
 // need_any: the caller needs a kernel of boundary class -1 (iteration budget, host rows)
 const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_diag, std::string *why, bool need_any = false,
-                         bool honour_index = true) {
+                         bool honour_index = true, int hetero = 0) {
   if (const char *env = honour_index ? std::getenv("FS_KERNEL_INDEX") : nullptr) {      // tests: one specific instantiation or nothing
     const int i = std::atoi(env);
-    if (i >= 0 && i < kNumEntries && entry_fits(kEntries[i], dtype, sec, N, usk, dsk, need_diag, need_any)) return &kEntries[i];
+    if (i >= 0 && i < kNumEntries && entry_fits(kEntries[i], dtype, sec, N, usk, dsk, need_diag, need_any, hetero)) return &kEntries[i];
     if (why) *why = "FS_KERNEL_INDEX=" + std::string(env) + " does not fit this batch";
     return nullptr;
   }
@@ -148,7 +152,7 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
   const bool general_only = gen && gen[0] == '1';
   const Entry *best = nullptr;
   for (const Entry &e : kEntries) {
-    if (!entry_fits(e, dtype, sec, N, usk, dsk, need_diag, need_any)) continue;
+    if (!entry_fits(e, dtype, sec, N, usk, dsk, need_diag, need_any, hetero)) continue;
     if (general_only && (!e.diag || e.bck >= 2)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
@@ -184,6 +188,11 @@ struct fs_batch {
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
   void *poly_x = nullptr, *poly_z = nullptr, *poly_lim = nullptr;
   int32_t *poly_n = nullptr;
+  size_t geo_reach_stride = 0, poly_reach_stride = 0;     // per-reach geometry (elements between the tables of two reaches), 0: shared
+  int32_t *reach_nodes = nullptr;       // [B] per-reach node counts (heterogeneous batch) or nullptr
+  void *reach_scheme = nullptr;         // [3][B] per-reach theta, dt, dx or nullptr
+  int32_t *reach_kinds = nullptr;       // [2][B] per-reach boundary kinds or nullptr
+  bool kinds_per_reach[2] = {false, false};
   void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
   void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
@@ -264,6 +273,9 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.geo_uniform = (const R *)b->geo_uniform; a.geo_table = (const R *)b->geo_table;
   a.n_override = (const R *)b->n_override;
   a.poly_x = (const R *)b->poly_x; a.poly_z = (const R *)b->poly_z; a.poly_lim = (const R *)b->poly_lim; a.poly_n = b->poly_n;
+  a.geo_reach_stride = (int64_t)b->geo_reach_stride; a.poly_reach_stride = (int64_t)b->poly_reach_stride;
+  a.reach_nodes = b->reach_nodes; a.reach_scheme = (const R *)b->reach_scheme;
+  a.reach_kinds = (b->kinds_per_reach[0] || b->kinds_per_reach[1]) ? b->reach_kinds : nullptr;
   fs::BCDesc<R> *bc[2] = {&a.us, &a.ds};
   for (int s = 0; s < 2; ++s) {
     bc[s]->kind = b->bc_kind[s]; bc[s]->stride = b->bc_stride[s];
@@ -279,8 +291,9 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
 int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
   TraceRange range_(iter_budget > 0 ? "flowsim:iterate" : "flowsim:step");
   std::string why;
+  const int hetero = (b->reach_nodes ? 1 : 0) | ((b->reach_scheme || b->kinds_per_reach[0] || b->kinds_per_reach[1]) ? 2 : 0);
   const Entry *k = pick_kernel(b->d.dtype, b->d.section_mode, b->d.n_nodes, b->bc_kind[0], b->bc_kind[1],
-                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE | FS_FLAG_MONITOR)) != 0, &why, iter_budget > 0);
+                               (b->d.flags & (FS_FLAG_HISTORY | FS_FLAG_TRACE | FS_FLAG_MONITOR)) != 0, &why, iter_budget > 0, true, hetero);
   if (!k && why.rfind("FS_KERNEL_INDEX", 0) == 0) return fail("fs_batch_step: " + why);
   if (!k && (b->bc_kind[0] == FS_BC_STORAGE_CURVE || b->bc_kind[1] == FS_BC_STORAGE_CURVE))
     return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
@@ -394,7 +407,8 @@ void fs_batch_destroy(fs_batch *b) {
   if (b->stream) (void)hipStreamSynchronize(b->stream);
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
-                  b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg};
+                  b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
+                  b->reach_scheme, b->reach_kinds};
   for (void *p : bufs) if (p) (void)hipFree(p);
   for (void *p : b->derived) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -433,8 +447,72 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
   FS_ON_DEVICE(b);
   {
     const std::vector<double> x = extend_table(table, b->d.n_nodes);
+    if (b->geo_reach_stride) { (void)hipFree(b->geo_table); b->geo_table = nullptr; b->geo_reach_stride = 0; }
     if (upload(b, &b->geo_table, x.data(), x.size())) return -1;
   }
+  if (n_main_override) {
+    if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
+  } else if (b->n_override) {
+    (void)hipFree(b->n_override); b->n_override = nullptr;
+  }
+  b->have_geo = true;
+  return 0;
+}
+
+// polylines of one channel: validated and transposed into the vertex-major device layout ([P][N]; unused slots repeat the last
+// vertex so that no lane ever reads NaN).  Returns an error text or nullptr.
+static const char *pack_polylines(const double *table, const int32_t *n_pts, int32_t max_pts, const double *x, const double *z,
+                                  const double *limits, size_t N, double *xt, double *zt, double *lim) {
+  const size_t P = max_pts;
+  for (size_t i = 0; i < N; ++i) {
+    const int c = n_pts[i];
+    if (c == 0) continue;
+    if (c < 2 || c > max_pts) return "fs_batch_set_geometry_irregular: n_pts must be 0 or 2..max_pts";
+    double zmin = z[i * P];
+    for (int j = 0; j < c; ++j) {
+      const double xv = x[i * P + j], zv = z[i * P + j];
+      if (!(xv == xv) || !(zv == zv)) return "x and z must have the same shape";            // cross_section.py:222 (NaN padding inside the count)
+      if (j && xv < x[i * P + j - 1]) return "fs_batch_set_geometry_irregular: x must be ascending (IrregularSection sorts it, cross_section.py:231)";
+      zmin = zv < zmin ? zv : zmin;
+    }
+    if (table[(size_t)FS_GEO_Z_BED * N + i] != zmin)
+      return "fs_batch_set_geometry_irregular: table row Z_BED must hold min(z) of a polyline node (IrregularSection.z_min)";
+    for (size_t j = 0; j < P; ++j) {
+      const size_t src = i * P + (j < (size_t)c ? j : (size_t)c - 1);
+      xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
+    }
+    lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
+  }
+  return nullptr;
+}
+
+// n_sets = 1: one channel shared by the batch; n_sets = B: one per reach (tables [B][NPARAM][N], n_pts [B][N], x / z [B][N][P],
+// limits [B][N][2])
+static int set_irregular(fs_batch *b, const double *table, const int32_t *n_pts, int32_t max_pts, const double *x, const double *z,
+                         const double *limits, const double *n_main_override, size_t n_sets) {
+  if (!b || !table || !n_pts || !x || !z || !limits) return fail("fs_batch_set_geometry_irregular: null argument");
+  if (b->d.section_mode != FS_SEC_IRREGULAR) return fail("fs_batch_set_geometry_irregular: batch was created with another section_mode");
+  if (max_pts < 2) return fail("fs_batch_set_geometry_irregular: max_pts must be >= 2");
+  FS_ON_DEVICE(b);
+  const size_t N = b->d.n_nodes, P = max_pts, per = (size_t)fs::FS_GEOX_NROWS * N;
+  std::vector<double> xt(n_sets * P * N, 0.0), zt(n_sets * P * N, 0.0), lim(n_sets * 2 * N, 0.0), tabs(n_sets * per);
+  for (size_t r = 0; r < n_sets; ++r) {
+    const double *tab_r = table + r * FS_GEO_NPARAM * N;
+    if (const char *err = pack_polylines(tab_r, n_pts + r * N, max_pts, x + r * N * P, z + r * N * P, limits + r * 2 * N, N,
+                                         xt.data() + r * P * N, zt.data() + r * P * N, lim.data() + r * 2 * N))
+      return fail(err);
+    const std::vector<double> ext = extend_table(tab_r, N);
+    std::memcpy(tabs.data() + r * per, ext.data(), per * sizeof(double));
+  }
+  void **old[] = {&b->geo_table, &b->poly_x, &b->poly_z, &b->poly_lim};
+  for (void **q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
+  if (b->poly_n) { (void)hipFree(b->poly_n); b->poly_n = nullptr; }
+  if (upload(b, &b->geo_table, tabs.data(), tabs.size()) || upload(b, &b->poly_x, xt.data(), xt.size()) ||
+      upload(b, &b->poly_z, zt.data(), zt.size()) || upload(b, &b->poly_lim, lim.data(), lim.size())) return -1;
+  HIP_TRY(hipMalloc((void **)&b->poly_n, n_sets * N * 4));
+  HIP_TRY(hipMemcpy(b->poly_n, n_pts, n_sets * N * 4, hipMemcpyHostToDevice));
+  b->geo_reach_stride = n_sets > 1 ? per : 0;
+  b->poly_reach_stride = n_sets > 1 ? P * N : 0;
   if (n_main_override) {
     if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
   } else if (b->n_override) {
@@ -447,48 +525,103 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int32_t *n_pts, int32_t max_pts,
                                     const double *x, const double *z, const double *limits,
                                     const double *n_main_override) {
-  if (!b || !table || !n_pts || !x || !z || !limits) return fail("fs_batch_set_geometry_irregular: null argument");
-  if (b->d.section_mode != FS_SEC_IRREGULAR) return fail("fs_batch_set_geometry_irregular: batch was created with another section_mode");
-  if (max_pts < 2) return fail("fs_batch_set_geometry_irregular: max_pts must be >= 2");
+  return set_irregular(b, table, n_pts, max_pts, x, z, limits, n_main_override, 1);
+}
+
+int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables, const int32_t *n_pts, int32_t max_pts,
+                                              const double *x, const double *z, const double *limits,
+                                              const double *n_main_override) {
+  if (!b) return fail("fs_batch_set_geometry_irregular: null argument");
+  if (b->d.n_reaches == 1) return set_irregular(b, tables, n_pts, max_pts, x, z, limits, n_main_override, 1);
+  return set_irregular(b, tables, n_pts, max_pts, x, z, limits, n_main_override, (size_t)b->d.n_reaches);
+}
+
+// One TrapezoidalSection table per reach: tables[B][FS_GEO_NPARAM][N] on the host -> [B][FS_GEOX_NROWS][N] on the device (a
+// reach's workgroup reads its own table, lanes along the nodes: coalesced; once per launch in the two-rows-per-lane kernels)
+int fs_batch_set_geometry_table_per_reach(fs_batch *b, const double *tables, const double *n_main_override) {
+  if (!b || !tables) return fail("fs_batch_set_geometry_table_per_reach: null argument");
+  if (b->d.section_mode != FS_SEC_TABLE) return fail("fs_batch_set_geometry_table_per_reach: batch was created with another section_mode");
   FS_ON_DEVICE(b);
-  const size_t N = b->d.n_nodes, P = max_pts;
-  // vertex-major copies [P][N]; unused slots repeat the last vertex so that no lane ever reads NaN
-  std::vector<double> xt(P * N, 0.0), zt(P * N, 0.0), lim(2 * N, 0.0);
-  for (size_t i = 0; i < N; ++i) {
-    const int c = n_pts[i];
-    if (c == 0) continue;
-    if (c < 2 || c > max_pts) return fail("fs_batch_set_geometry_irregular: n_pts must be 0 or 2..max_pts");
-    double zmin = z[i * P];
-    for (int j = 0; j < c; ++j) {
-      const double xv = x[i * P + j], zv = z[i * P + j];
-      if (!(xv == xv) || !(zv == zv)) return fail("x and z must have the same shape");            // cross_section.py:222 (NaN padding inside the count)
-      if (j && xv < x[i * P + j - 1]) return fail("fs_batch_set_geometry_irregular: x must be ascending (IrregularSection sorts it, cross_section.py:231)");
-      zmin = zv < zmin ? zv : zmin;
-    }
-    if (table[(size_t)FS_GEO_Z_BED * N + i] != zmin)
-      return fail("fs_batch_set_geometry_irregular: table row Z_BED must hold min(z) of a polyline node (IrregularSection.z_min)");
-    for (size_t j = 0; j < P; ++j) {
-      const size_t src = i * P + (j < (size_t)c ? j : (size_t)c - 1);
-      xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
-    }
-    lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes, per = (size_t)fs::FS_GEOX_NROWS * N;
+  std::vector<double> all(B * per);
+  for (size_t r = 0; r < B; ++r) {
+    const std::vector<double> x = extend_table(tables + r * FS_GEO_NPARAM * N, N);
+    std::memcpy(all.data() + r * per, x.data(), per * sizeof(double));
   }
-  {
-    const std::vector<double> x = extend_table(table, N);
-    if (upload(b, &b->geo_table, x.data(), x.size())) return -1;
-  }
-  if (b->poly_x) { (void)hipFree(b->poly_x); b->poly_x = nullptr; }
-  if (b->poly_z) { (void)hipFree(b->poly_z); b->poly_z = nullptr; }
-  if (upload(b, &b->poly_x, xt.data(), P * N) || upload(b, &b->poly_z, zt.data(), P * N) ||
-      upload(b, &b->poly_lim, lim.data(), 2 * N)) return -1;
-  if (!b->poly_n) HIP_TRY(hipMalloc((void **)&b->poly_n, N * 4));
-  HIP_TRY(hipMemcpy(b->poly_n, n_pts, N * 4, hipMemcpyHostToDevice));
+  if (b->geo_table) { (void)hipFree(b->geo_table); b->geo_table = nullptr; }
+  if (upload(b, &b->geo_table, all.data(), all.size())) return -1;
+  b->geo_reach_stride = per;
   if (n_main_override) {
-    if (upload(b, &b->n_override, n_main_override, b->d.n_reaches)) return -1;
+    if (upload(b, &b->n_override, n_main_override, B)) return -1;
   } else if (b->n_override) {
     (void)hipFree(b->n_override); b->n_override = nullptr;
   }
   b->have_geo = true;
+  return 0;
+}
+
+int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes) {
+  if (!b) return fail("null handle");
+  FS_ON_DEVICE(b);
+  const size_t B = b->d.n_reaches;
+  if (!n_nodes) {
+    if (b->reach_nodes) { (void)hipFree(b->reach_nodes); b->reach_nodes = nullptr; }
+    return 0;
+  }
+  for (size_t r = 0; r < B; ++r)
+    if (n_nodes[r] < 2 || n_nodes[r] > b->d.n_nodes) return fail("fs_batch_set_reach_nodes: every reach needs 2 <= nodes <= n_nodes of the batch");
+  if (!b->reach_nodes) HIP_TRY(hipMalloc((void **)&b->reach_nodes, B * 4));
+  HIP_TRY(hipMemcpy(b->reach_nodes, n_nodes, B * 4, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx) {
+  if (!b) return fail("null handle");
+  FS_ON_DEVICE(b);
+  const size_t B = b->d.n_reaches;
+  if (!theta && !dt && !dx) {
+    if (b->reach_scheme) { (void)hipFree(b->reach_scheme); b->reach_scheme = nullptr; }
+    return 0;
+  }
+  if (!b->have_scheme) return fail("fs_batch_set_reach_scheme: call fs_batch_set_scheme first (tolerance, max_iter and the values of the arrays left NULL)");
+  std::vector<double> v(3 * B);
+  for (size_t r = 0; r < B; ++r) {
+    v[r] = theta ? theta[r] : b->theta; v[B + r] = dt ? dt[r] : b->dt; v[2 * B + r] = dx ? dx[r] : b->dx;
+    if (!(v[B + r] > 0) || !(v[2 * B + r] > 0)) return fail("fs_batch_set_reach_scheme: dt and dx must be positive");
+  }
+  if (b->reach_scheme) { (void)hipFree(b->reach_scheme); b->reach_scheme = nullptr; }
+  return upload(b, &b->reach_scheme, v.data(), v.size());
+}
+
+int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target) {
+  if (!b || !kinds || !params) return fail("fs_batch_set_bc_per_reach: null argument");
+  if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc_per_reach: side must be FS_UPSTREAM or FS_DOWNSTREAM");
+  FS_ON_DEVICE(b);
+  const size_t B = b->d.n_reaches;
+  bool need_target = false;
+  for (size_t r = 0; r < B; ++r) {
+    if (kinds[r] < 0 || kinds[r] > FS_BC_STORAGE) return fail("fs_batch_set_bc_per_reach: kinds FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE only");
+    if (kinds[r] == FS_BC_STORAGE && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
+    need_target = need_target || kinds[r] == FS_BC_FLOW_HYDROGRAPH || kinds[r] == FS_BC_STAGE_HYDROGRAPH;
+  }
+  if (need_target && !target) return fail("Insufficient arguments for boundary condition.");                     // boundary.py:87
+  if (b->bc_params[side]) { (void)hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
+  if (b->bc_target[side]) { (void)hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
+  if (upload(b, &b->bc_params[side], params, (size_t)FS_BC_MAX_PARAMS * B)) return -1;
+  if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
+  if (!b->reach_kinds) {
+    HIP_TRY(hipMalloc((void **)&b->reach_kinds, 2 * B * 4));
+    HIP_TRY(hipMemset(b->reach_kinds, 0, 2 * B * 4));
+  }
+  HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, kinds, B * 4, hipMemcpyHostToDevice));
+  // the other side, if it was set for the whole batch, keeps its one kind in every slot
+  const int other = 1 - side;
+  if (b->have_bc[other] && !b->kinds_per_reach[other]) {
+    std::vector<int32_t> same(B, b->bc_kind[other]);
+    HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)other * B, same.data(), B * 4, hipMemcpyHostToDevice));
+  }
+  b->bc_kind[side] = kinds[0]; b->bc_stride[side] = 1; b->kinds_per_reach[side] = true;
+  b->have_bc[side] = true;
   return 0;
 }
 
@@ -536,6 +669,11 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
   if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
   b->bc_kind[side] = kind; b->bc_stride[side] = per_reach ? 1 : 0;
   b->have_bc[side] = true;
+  b->kinds_per_reach[side] = false;
+  if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
+    std::vector<int32_t> same(B, kind);
+    HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -795,6 +933,7 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
     fs::DeriveArgs<double> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const double *)b->hist_h,
                              (const double *)b->hist_Q, (const double *)b->geo_uniform, (const double *)b->geo_table,
                              (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
+                             (int64_t)b->geo_reach_stride, (int64_t)b->poly_reach_stride,
                              (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
                              (double *)dev[5], (double *)dev[6], (double *)dev[7]};
     hipLaunchKernelGGL((fs::derive_fields_kernel<double, 2>), grid, dim3(256), 0, b->stream, a);
@@ -802,6 +941,7 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
     fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
                             (const float *)b->hist_Q, (const float *)b->geo_uniform, (const float *)b->geo_table,
                             (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
+                            (int64_t)b->geo_reach_stride, (int64_t)b->poly_reach_stride,
                             (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
                             (float *)dev[5], (float *)dev[6], (float *)dev[7]};
     hipLaunchKernelGGL((fs::derive_fields_kernel<float, 4>), grid, dim3(256), 0, b->stream, a);

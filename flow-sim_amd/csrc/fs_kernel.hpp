@@ -153,7 +153,14 @@ template <typename R> struct KernelArgs {
   R *hk, *Qk;              // [B][N] accepted state of the current level (in: level0, out: level0+n_steps)
   R *hg, *Qg;              // [B][N] Newton start vector for the next level
   const R *geo_uniform;    // RECT_UNIFORM: [FS_RU_NPARAM][B]
-  const R *geo_table;      // TABLE: [FS_GEO_NPARAM][N]
+  const R *geo_table;      // TABLE: [FS_GEOX_NROWS][N], shared by the batch, or one such table per reach (geo_reach_stride)
+  int64_t geo_reach_stride;      // elements between the tables of consecutive reaches (0: one table for the whole batch)
+  int64_t poly_reach_stride;     // IRREGULAR: the same for poly_x / poly_z (P * N); poly_lim and poly_n follow with 2 N and N
+  // heterogeneous batches (fs_batch_set_reach_*): each reach its own channel length, grid and scheme - what the reference
+  // builds per Channel / Solver (channel.py:213-241, solver.py:34-38,53-55)
+  const int32_t *reach_nodes;    // [B] or nullptr: nodes of each reach (<= N; N stays the row stride of every [B][N] array)
+  const R *reach_scheme;         // [3][B] or nullptr: theta, dt, dx of each reach
+  const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE)
   const R *n_override;     // TABLE: [B] or nullptr
   const R *poly_x, *poly_z;      // IRREGULAR: [P][N] polyline stations / elevations (vertex-major)
   const R *poly_lim;             // IRREGULAR: [2][N] roughness strip limits
@@ -182,13 +189,13 @@ __device__ __forceinline__ BCDesc<R> pinned(const BCDesc<R> &bc) {
 template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
   static constexpr bool kConstT = true;      // dA/dh = b everywhere: no per-node top width to keep
   R b, rb, n, rn, z_us, z_ds, inv_nm1, dz;
-  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int n_nodes) {
     b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
     n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
     z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach];
     z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
     rb = R(1) / b; rn = R(1) / n;
-    inv_nm1 = R(1) / R(a.N - 1);
+    inv_nm1 = R(1) / R(n_nodes - 1);
     dz = (z_ds - z_us) * inv_nm1;
   }
   __device__ __forceinline__ R bed_step(int) const { return dz; }   // bed(node+1) - bed(node)
@@ -221,7 +228,7 @@ template <typename R> struct Geometry<R, FS_SEC_RECT_UNIFORM> {
 template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
   static constexpr bool kConstT = false;
   R b, m, sm2, n, rn, z_us, z_ds, inv_nm1, dz;
-  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int n_nodes) {
     b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
     n = a.geo_uniform[(size_t)FS_RU_MANNING * a.B + reach];
     rn = R(1) / n;
@@ -229,7 +236,7 @@ template <typename R> struct Geometry<R, FS_SEC_TRAP_UNIFORM> {
     z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
     m = a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach];
     sm2 = R(2) * sqrt_(R(1) + m * m);
-    inv_nm1 = R(1) / R(a.N - 1);
+    inv_nm1 = R(1) / R(n_nodes - 1);
     dz = (z_ds - z_us) * inv_nm1;
   }
   __device__ __forceinline__ R bed_step(int) const { return dz; }
@@ -260,8 +267,8 @@ template <typename R> struct Geometry<R, FS_SEC_TABLE> {
   int N;
   R n_over, rn_over, k15_over;      // per-reach main-channel Manning n (ensembles), its reciprocal and its -1.5 power
   bool has_over;
-  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
-    tab = a.geo_table; N = a.N;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int) {
+    tab = a.geo_table + (size_t)reach * a.geo_reach_stride; N = a.N;       // (N: the row stride of the table)
     has_over = a.n_override != nullptr;
     n_over = has_over ? a.n_override[reach] : R(1);
     rn_over = R(1) / n_over; k15_over = pm15_(n_over);
@@ -306,9 +313,11 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   Geometry<R, FS_SEC_TABLE> tb;
   const R *px, *pz, *plim;
   const int32_t *pn;
-  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach) {
-    tb.init(a, reach);
-    px = a.poly_x; pz = a.poly_z; plim = a.poly_lim; pn = a.poly_n;
+  __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int n_nodes) {
+    tb.init(a, reach, n_nodes);
+    const bool own = a.poly_reach_stride != 0;
+    px = a.poly_x + (size_t)reach * a.poly_reach_stride; pz = a.poly_z + (size_t)reach * a.poly_reach_stride;
+    plim = a.poly_lim + (own ? (size_t)reach * 2 * a.N : 0); pn = a.poly_n + (own ? (size_t)reach * a.N : 0);
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }
   __device__ __forceinline__ R rT_const() const { return R(0); }
@@ -410,14 +419,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     it_entry = a.it_done[reach];
     if (it_entry < 0) return;                 // this reach has closed the level: it waits for the others (whole workgroup)
   }
-  const int N = a.N, NC = N - 1;
+  // nodes of this reach; NS = a.N stays the row stride of every [B][N] array (heterogeneous batches: RAGGED kernels only)
+  const int NS = a.N;
+  const int N = (RAGGED && a.reach_nodes) ? a.reach_nodes[reach] : a.N, NC = N - 1;
   const int s0 = t * M;                       // first node / row of this lane
   const int tD = RAGGED ? NC / M : T - 1;     // lane that owns node N-1 and the downstream boundary row ...
   const int jD = RAGGED ? NC - tD * M : M - 1;   // ... as its local node / row jD (0..M-1)
-  const size_t base = (size_t)reach * N;
+  const size_t base = (size_t)reach * NS;
 
   Geo geo;
-  geo.init(a, reach);
+  geo.init(a, reach, N);
   // node terms of the lane's local node j (0..M); FS_REG_GEO: from section parameters loaded once per launch
   SecParams<R> secs[kRegGeo ? M + 1 : 1];
   if constexpr (kRegGeo) {
@@ -429,10 +440,12 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     else return geo.terms(min(s0 + j, N - 1), hh, QQ);
   };
 
-  const R th = a.theta, dt = a.dt;
+  const bool own_scheme = BCK <= 0 && a.reach_scheme != nullptr;          // (the kernels compiled for one boundary pair are the benchmark shapes)
+  const R th = own_scheme ? a.reach_scheme[reach] : a.theta, dt = own_scheme ? a.reach_scheme[(size_t)a.B + reach] : a.dt;
+  const R dx_ = own_scheme ? a.reach_scheme[(size_t)2 * a.B + reach] : a.dx;
   R r2dt = R(1) / (R(2) * dt);
-  R cq = th / a.dx;                           // theta/dx
-  const R cqk = (R(1) - th) / a.dx;           // (1-theta)/dx
+  R cq = th / dx_;                            // theta/dx
+  const R cqk = (R(1) - th) / dx_;            // (1-theta)/dx
   R hth = R(0.5) * th;
   const R hthk = R(0.5) * (R(1) - th);
   R g = R(kG);
@@ -522,9 +535,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   // last wave; a global load there costs more than the row itself), the hydrograph value of a level
   // is fetched when the level starts.
   BCDesc<R> usd = a.us, dsd = a.ds;
+  if (BCK <= 0 && a.reach_kinds) { usd.kind = a.reach_kinds[reach]; dsd.kind = a.reach_kinds[(size_t)a.B + reach]; }
   if (t < 2 * FS_BC_MAX_PARAMS) {
     const int side = t / FS_BC_MAX_PARAMS, i = t - side * FS_BC_MAX_PARAMS;
-    const BCDesc<R> &src = side ? a.ds : a.us;
+    BCDesc<R> src = side ? a.ds : a.us;
+    src.kind = side ? dsd.kind : usd.kind;
     static constexpr int kCount[] = {0, 1, 1, 2, 4, 5, 10, 5};
     if (src.kind <= FS_BC_STORAGE && i < kCount[src.kind]) sm.bcp[side][i] = bc_param(src, i, reach, a.B);
     if (src.kind == FS_BC_NORMAL_DEPTH && i == 2) {        // derived: sign(S0) sqrt|S0| (hydraulics.py:4-13)
@@ -536,7 +551,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
 
   // a compile-time constant in the kernels compiled for a boundary pair
-  const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(a.ds.kind);
+  const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(dsd.kind);
   R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
   // FS_ILL_CONDITIONED is a warning that sticks to the reach, not a failure: the run goes on (and a later launch finds it here)
@@ -1028,8 +1043,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           // and, if a history is kept, at every level.  (A transposed, fully coalesced write-back
           // through LDS was measured too: no gain, three extra barriers.)
           const bool last = (step == a.n_steps - 1);
-          R *const hh_p = (DIAG && a.hist_h) ? a.hist_h + ((size_t)level * a.B + reach) * N + s0 : nullptr;
-          R *const hQ_p = (DIAG && a.hist_h) ? a.hist_Q + ((size_t)level * a.B + reach) * N + s0 : nullptr;
+          R *const hh_p = (DIAG && a.hist_h) ? a.hist_h + ((size_t)level * a.B + reach) * NS + s0 : nullptr;
+          R *const hQ_p = (DIAG && a.hist_h) ? a.hist_Q + ((size_t)level * a.B + reach) * NS + s0 : nullptr;
           if (last || hh_p) {
 #pragma unroll
             for (int j = 0; j < M; ++j) {
@@ -1118,6 +1133,7 @@ template <typename R> struct DeriveArgs {
   const R *geo_uniform, *geo_table;
   const R *poly_x, *poly_z;       // IRREGULAR (see KernelArgs)
   const int32_t *poly_n;
+  int64_t geo_reach_stride, poly_reach_stride;      // per-reach tables (see KernelArgs), 0: shared
   R *level, *area, *top, *froude, *vel, *cel, *amp, *peak;   // [n][B][N] (peak: [B][N]) or nullptr
 };
 
@@ -1160,12 +1176,15 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
     const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
     pnode[e].n = 0;
     if (a.section_mode == FS_SEC_TABLE || a.section_mode == FS_SEC_IRREGULAR) {
-      auto g = [&](int row) { return a.geo_table[(size_t)row * a.N + node]; };
+      auto g = [&](int row) { return a.geo_table[(size_t)reach * a.geo_reach_stride + (size_t)row * a.N + node]; };
       s[e].z = g(FS_GEO_Z_BED); s[e].b = g(FS_GEO_B_MAIN); s[e].m = g(FS_GEO_M_MAIN);
       s[e].compound = g(FS_GEO_IS_COMPOUND) > R(0.5);
       s[e].hbf = g(FS_GEO_H_BANKFULL); s[e].bl = g(FS_GEO_B_FP_LEFT); s[e].br = g(FS_GEO_B_FP_RIGHT); s[e].mfp = g(FS_GEO_M_FP);
-      if (a.section_mode == FS_SEC_IRREGULAR && a.poly_n[node] > 0) {
-        pnode[e].x = a.poly_x + node; pnode[e].z = a.poly_z + node; pnode[e].stride = a.N; pnode[e].n = a.poly_n[node];
+      if (a.section_mode == FS_SEC_IRREGULAR) {
+        const size_t po = (size_t)reach * a.poly_reach_stride, no = a.poly_reach_stride ? (size_t)reach * a.N : 0;
+        if (a.poly_n[no + node] > 0) {
+          pnode[e].x = a.poly_x + po + node; pnode[e].z = a.poly_z + po + node; pnode[e].stride = a.N; pnode[e].n = a.poly_n[no + node];
+        }
       }
     } else {
       const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];

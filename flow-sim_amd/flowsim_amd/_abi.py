@@ -14,6 +14,7 @@ F64, F32 = 0, 1
 SEC_RECT_UNIFORM, SEC_TRAP_UNIFORM, SEC_TABLE, SEC_IRREGULAR = 0, 1, 2, 3
 RU_WIDTH, RU_MANNING, RU_Z_US, RU_Z_DS, RU_NPARAM = 0, 1, 2, 3, 4
 TU_SIDE_SLOPE, TU_NPARAM = 4, 5
+BC_MAX_PARAMS = 10
 GEO_ROWS = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf",
             "b_fp_l", "b_fp_r", "m_fp", "curvature")
 GEO_NPARAM = len(GEO_ROWS)
@@ -27,7 +28,7 @@ OK, MAX_ITER, NAN, STORAGE_RANGE, ILL_CONDITIONED = 0, 1, 2, 3, 4
 FLAG_HISTORY, FLAG_TRACE, FLAG_MONITOR = 1, 2, 4
 TRACE_CAP = 64
 DERIVE_ALL = 255
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class BatchDesc(C.Structure):
@@ -52,6 +53,11 @@ SIGNATURES = {
     "fs_batch_set_geometry_table": (C.c_int, [_P, _D, _D]),
     "fs_batch_set_geometry_irregular": (C.c_int, [_P, _D, _I, C.c_int32, _D, _D, _D, _D]),
     "fs_batch_set_bc": (C.c_int, [_P, C.c_int32, C.c_int32, _D, C.c_int32, C.c_int32, _D]),
+    "fs_batch_set_geometry_table_per_reach": (C.c_int, [_P, _D, _D]),
+    "fs_batch_set_geometry_irregular_per_reach": (C.c_int, [_P, _D, _I, C.c_int32, _D, _D, _D, _D]),
+    "fs_batch_set_reach_nodes": (C.c_int, [_P, _I]),
+    "fs_batch_set_reach_scheme": (C.c_int, [_P, _D, _D, _D]),
+    "fs_batch_set_bc_per_reach": (C.c_int, [_P, C.c_int32, _I, _D, _D]),
     "fs_batch_set_state": (C.c_int, [_P, _D, _D]),
     "fs_batch_set_state_uniform": (C.c_int, [_P, _D, _D]),
     "fs_batch_step": (C.c_int, [_P, C.c_int32]),

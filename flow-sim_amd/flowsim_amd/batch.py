@@ -88,34 +88,73 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_set_geometry_uniform(self._h, _dptr(p)), "set_geometry_uniform")
 
     def set_geometry_table(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):
-        tab = np.empty((A.GEO_NPARAM, self.N), dtype=np.float64)
+        """geo[k]: [N] (one channel shared by the batch) or [B, N] (one channel per reach: geometry ensembles, different
+        rivers; rows of a shorter reach padded by repeating its last node, see set_reach_nodes)"""
+        per_reach = any(np.ndim(geo[k]) == 2 for k in A.GEO_ROWS)
+        tab = np.empty((self.B, A.GEO_NPARAM, self.N) if per_reach else (A.GEO_NPARAM, self.N), dtype=np.float64)
         for i, k in enumerate(A.GEO_ROWS):
-            tab[i] = np.asarray(geo[k], dtype=np.float64)
+            if per_reach:
+                tab[:, i, :] = np.broadcast_to(np.asarray(geo[k], dtype=np.float64), (self.B, self.N))
+            else:
+                tab[i] = np.asarray(geo[k], dtype=np.float64)
         ov = None
         if n_main_override is not None:
             ov = np.ascontiguousarray(n_main_override, dtype=np.float64)
             assert ov.shape == (self.B,)
-        A.check(self._lib.fs_batch_set_geometry_table(self._h, _dptr(tab), _dptr(ov) if ov is not None else None),
-                "set_geometry_table")
+        fn = self._lib.fs_batch_set_geometry_table_per_reach if per_reach else self._lib.fs_batch_set_geometry_table
+        A.check(fn(self._h, _dptr(tab), _dptr(ov) if ov is not None else None), "set_geometry_table")
+
+    def set_reach_nodes(self, n_nodes):
+        """per-reach node counts (<= N of the batch): each reach its own channel length / grid (solver.py:34-38, :53-55)"""
+        n = np.ascontiguousarray(n_nodes, dtype=np.int32)
+        assert n.shape == (self.B,)
+        A.check(self._lib.fs_batch_set_reach_nodes(self._h, n.ctypes.data_as(A._I)), "set_reach_nodes")
+
+    def set_reach_scheme(self, theta=None, dt=None, dx=None):
+        """per-reach theta / time step / spatial step (arrays [B]; None: the batch-wide value of set_scheme)"""
+        arrs = [None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (self.B,))) for v in (theta, dt, dx)]
+        A.check(self._lib.fs_batch_set_reach_scheme(self._h, *[None if a is None else _dptr(a) for a in arrs]), "set_reach_scheme")
+
+    def set_boundary_per_reach(self, side: int, specs):
+        """one BoundarySpec per reach, kinds free to differ (the closed-form kinds, BC_FLOW_HYDROGRAPH .. BC_STORAGE);
+        a spec's target is [n_levels] (sampled at that reach's own k * dt)"""
+        assert len(specs) == self.B
+        kinds = np.array([s.kind for s in specs], dtype=np.int32)
+        p = np.zeros((A.BC_MAX_PARAMS, self.B), dtype=np.float64)
+        tgt = None
+        for r, s in enumerate(specs):
+            for i, name in enumerate(_KIND_PARAMS[s.kind]):
+                p[i, r] = float(s.params[name])
+            if s.target is not None:
+                if tgt is None:
+                    tgt = np.zeros((self.L, self.B), dtype=np.float64)
+                t = np.asarray(s.target, dtype=np.float64).reshape(-1)
+                n = min(self.L, t.shape[0])
+                tgt[:n, r] = t[:n]
+                tgt[n:, r] = t[n - 1]
+        A.check(self._lib.fs_batch_set_bc_per_reach(self._h, side, kinds.ctypes.data_as(A._I), _dptr(p),
+                                                    _dptr(tgt) if tgt is not None else None), "set_boundary_per_reach")
 
     def set_geometry_irregular(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):
         """geo: the TABLE rows plus irr_x / irr_z [N, P] (rows padded beyond irr_npts), irr_npts [N]
         (0 = trapezoid-family node) and irr_limits [N, 2] (IrregularSection.left/right_fp_limit)."""
-        tab = np.empty((A.GEO_NPARAM, self.N), dtype=np.float64)
+        per_reach = np.ndim(geo["irr_npts"]) == 2          # one channel per reach: irr_npts [B, N], irr_x / irr_z [B, N, P], irr_limits [B, N, 2]
+        lead = (self.B,) if per_reach else ()
+        tab = np.empty(lead + (A.GEO_NPARAM, self.N), dtype=np.float64)
         for i, k in enumerate(A.GEO_ROWS):
-            tab[i] = np.asarray(geo[k], dtype=np.float64)
+            tab[..., i, :] = np.asarray(geo[k], dtype=np.float64)
         cnt = np.ascontiguousarray(geo["irr_npts"], dtype=np.int32)
         x = np.ascontiguousarray(geo["irr_x"], dtype=np.float64)
         z = np.ascontiguousarray(geo["irr_z"], dtype=np.float64)
         lim = np.ascontiguousarray(geo["irr_limits"], dtype=np.float64)
-        assert cnt.shape == (self.N,) and x.shape == z.shape and x.shape[0] == self.N and lim.shape == (self.N, 2)
+        assert cnt.shape == lead + (self.N,) and x.shape == z.shape and x.shape[:-1] == lead + (self.N,) and lim.shape == lead + (self.N, 2)
         ov = None
         if n_main_override is not None:
             ov = np.ascontiguousarray(n_main_override, dtype=np.float64)
             assert ov.shape == (self.B,)
-        A.check(self._lib.fs_batch_set_geometry_irregular(
-            self._h, _dptr(tab), cnt.ctypes.data_as(A._I), x.shape[1], _dptr(x), _dptr(z), _dptr(lim),
-            _dptr(ov) if ov is not None else None), "set_geometry_irregular")
+        fn = self._lib.fs_batch_set_geometry_irregular_per_reach if per_reach else self._lib.fs_batch_set_geometry_irregular
+        A.check(fn(self._h, _dptr(tab), cnt.ctypes.data_as(A._I), x.shape[-1], _dptr(x), _dptr(z), _dptr(lim),
+                   _dptr(ov) if ov is not None else None), "set_geometry_irregular")
 
     def set_boundary(self, side: int, spec: BoundarySpec):
         if spec.kind == A.BC_HOST_ROW:

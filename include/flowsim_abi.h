@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS_ABI_VERSION 2
+#define FS_ABI_VERSION 3
 
 typedef struct fs_batch fs_batch;
 
@@ -170,6 +170,29 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int32_t *n_pts, int32_t max_pts,
                                     const double *x, const double *z, const double *limits,
                                     const double *n_main_override);
+
+/* Heterogeneous batches: every reach its own channel - what the reference builds per Channel / Solver object
+ * (channel.py:213-241 node sections, cross_section.py:857-930 interpolation, solver.py:34-38,53-55 grid) - so that different
+ * rivers, or a geometry Monte-Carlo of one river (bed levels, widths, bankfull depths), step in one launch.
+ *   fs_batch_set_geometry_table_per_reach      tables[B][FS_GEO_NPARAM][N]: one TrapezoidalSection table per reach (FS_SEC_TABLE);
+ *   fs_batch_set_geometry_irregular_per_reach  the same for FS_SEC_IRREGULAR: tables[B][FS_GEO_NPARAM][N], n_pts[B][N],
+ *                                              x / z [B][N][max_pts], limits[B][N][2];
+ *   fs_batch_set_reach_nodes                   n_nodes[B], 2 <= n_nodes[r] <= N of the batch (NULL: all N): reach r uses the
+ *                                              first n_nodes[r] entries of its rows of every [B][N] array (state, tables - pad the
+ *                                              rest with the last node's values -, history); entries beyond are left untouched;
+ *   fs_batch_set_reach_scheme                  theta[B], dt[B], dx[B] (any may be NULL: the batch-wide value of
+ *                                              fs_batch_set_scheme, which is called first); tolerance and max_iter stay batch-wide;
+ *   fs_batch_set_bc_per_reach                  kinds[B] (FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE), params[FS_BC_MAX_PARAMS][B] (row i
+ *                                              = parameter i of the reach's own kind, unused rows ignored), target[max_levels][B].
+ * Time level k of reach r is t = k * dt[r]: targets are sampled per reach.  These batches run on the general kernels (run-time
+ * boundary switch, ragged node counts); the kinds FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW stay batch-wide (fs_batch_set_bc). */
+int fs_batch_set_geometry_table_per_reach(fs_batch *b, const double *tables, const double *n_main_override);
+int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables, const int32_t *n_pts, int32_t max_pts,
+                                              const double *x, const double *z, const double *limits,
+                                              const double *n_main_override);
+int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes);
+int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx);
+int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target);
 
 /* one boundary (Boundary.__init__, boundary.py:10-46).  params[n_params] when per_reach == 0,
  * params[n_params][B] otherwise.  target[max_levels][B] (value at t = level*dt, i.e.

@@ -99,3 +99,25 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     b.set_boundary(A.DOWNSTREAM, merge_specs([boundary_spec(p.ds, p.nt) for p in problems], B))
     b.set_state(np.stack([p.h0 for p in problems]), np.stack([p.Q0 for p in problems]))
     return b
+
+
+def hetero_batch_from_problems(problems, mode="table", history=True):
+    """ONE batch from oracle Problems that share nothing but the tolerance: every reach its own channel (node table), node
+    count, theta / dt / dx, boundary kinds and number of levels (fs_batch_set_geometry_table_per_reach, fs_batch_set_reach_nodes,
+    fs_batch_set_reach_scheme, fs_batch_set_bc_per_reach).  Rows of shorter reaches are padded with their last node."""
+    B, N, L = len(problems), max(p.N for p in problems), max(p.nt for p in problems)
+    p0 = problems[0]
+    assert all(p.tol == p0.tol and p.max_iter == p0.max_iter for p in problems)
+
+    def pad(a):
+        a = np.asarray(a, dtype=np.float64)
+        return np.concatenate([a, np.full(N - len(a), a[-1])])
+    b = PreissmannBatch(B, N, L, section_mode=mode, history=history)
+    b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
+    b.set_geometry_table({k: np.stack([pad(p.geo[k]) for p in problems]) for k in A.GEO_ROWS})
+    b.set_reach_nodes([p.N for p in problems])
+    b.set_reach_scheme([p.theta for p in problems], [p.dt for p in problems], [p.dx for p in problems])
+    b.set_boundary_per_reach(A.UPSTREAM, [boundary_spec(p.us, p.nt) for p in problems])
+    b.set_boundary_per_reach(A.DOWNSTREAM, [boundary_spec(p.ds, p.nt) for p in problems])
+    b.set_state(np.stack([pad(p.h0) for p in problems]), np.stack([pad(p.Q0) for p in problems]))
+    return b

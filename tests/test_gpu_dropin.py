@@ -9,6 +9,7 @@ import pytest
 from conftest import GOLDEN
 from oracle import preissmann_oracle as O
 import case_builders as CB
+from flowsim_amd import PreissmannBatch, _abi as A
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-8
@@ -200,6 +201,40 @@ def test_restart_continues_bit_exactly():
             assert np.array_equal(c.iterations(k + 1, nt - 1 - k), want[1][k + 1:])
             for x, y in zip(c.state() + c.guess(), want[2] + want[3]):
                 assert np.array_equal(x, y)
+
+
+def test_bed_level_monte_carlo_in_one_launch_equals_members_run_singly():
+    """SURVEY 8b per-reach geometry: 4 096 members of cases/gerd_roseires, each with its own perturbed bed profile and
+    bankfull depths (fs_batch_set_geometry_table_per_reach), in ONE launch; eight of them run alone - through the shared-table
+    entry point, as a batch of one - give the same bits."""
+    from fixture_batch import boundary_spec
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "gerd.npz"))
+    p = O.problem_from_fixture(fx, meta)
+    B, K = 4096, 4
+    rng = np.random.default_rng(20260304)
+    x = np.linspace(0.0, 1.0, p.N)
+    bump = 0.15 * np.sin(2 * np.pi * (rng.uniform(0.5, 3.0, (B, 1)) * x[None] + rng.uniform(0, 1, (B, 1)))) * rng.uniform(0, 1, (B, 1))
+    geo = {k: np.broadcast_to(p.geo[k], (B, p.N)).copy() for k in A.GEO_ROWS}
+    geo["z_bed"] += bump
+    geo["h_bf"] *= 1.0 + 0.1 * rng.uniform(-1, 1, (B, 1))
+    geo["b_main"] *= 1.0 + 0.05 * rng.uniform(-1, 1, (B, 1))
+
+    def run(tables, n):
+        with PreissmannBatch(n, p.N, K + 1, section_mode="table") as b:
+            b.set_scheme(p.theta, p.dt, p.dx, p.tol, p.max_iter)
+            b.set_geometry_table(tables)
+            b.set_boundary(A.UPSTREAM, boundary_spec(p.us, p.nt)); b.set_boundary(A.DOWNSTREAM, boundary_spec(p.ds, p.nt))
+            b.set_state(np.broadcast_to(p.h0, (n, p.N)), np.broadcast_to(p.Q0, (n, p.N)))
+            b.step(K)
+            return b.hydrographs(0, K + 1), b.iterations(0, K + 1), b.state(), b.status(), b.kernel_index()
+    hyd, its, (h, Q), st, kidx = run(geo, B)
+    assert np.all(st == 0)
+    assert np.ptp(hyd[K, 0, :]) > 1e-4                                       # the members do differ
+    for r in (0, 1, 7, 63, 64, 1000, 4094, 4095):
+        hyd1, its1, (h1, Q1), st1, kidx1 = run({k: geo[k][r] for k in A.GEO_ROWS}, 1)
+        assert kidx1 == kidx and st1[0] == 0
+        assert np.array_equal(hyd1[:, :, 0], hyd[:, :, r]) and np.array_equal(its1[:, 0], its[:, r])
+        assert np.array_equal(h1[0], h[r]) and np.array_equal(Q1[0], Q[r])
 
 
 def test_restart_guards():

@@ -90,6 +90,34 @@ def test_kernel_reproduces_the_reference(case):
             compare(h[:, 0], Q[:, 0], b.iterations(0, p.nt)[:, 0], fx, m)
 
 
+@pytest.mark.gpu
+def test_kernel_reproduces_the_trapezoid_family_cases_as_three_heterogeneous_batches():
+    """The same cases, not one batch per channel but three batches in all (grouped by size): every reach of a batch its own
+    node table, node count (2 ... 257), theta, time and space step, boundary kinds and number of levels - what the reference
+    builds per Channel / Solver object (channel.py:213-241, solver.py:34-38,53-55), here as per-reach tables of one launch
+    (geometry [param][node][reach])."""
+    from fixture_batch import hetero_batch_from_problems
+    fam = [(i, fx, m) for i, fx, m in CASES if m["family"] != "polyline" and m["ds_kind"] != "storage_curve"]
+    assert len(fam) >= 48 or SOAK
+    groups = {}
+    for c in fam:
+        groups.setdefault(0 if c[2]["N"] <= 33 else (1 if c[2]["N"] <= 129 else 2), []).append(c)
+    assert len(groups) <= 3
+    for members in groups.values():
+        probs = [O.problem_from_fixture(fx, m) for _, fx, m in members]
+        kinds = {(p.us.kind, p.ds.kind, p.ds.rc_type, p.ds.storage is not None) for p in probs}
+        assert len(kinds) >= 4 and len({p.N for p in probs}) >= 2 and len({p.dt for p in probs}) >= 2     # a mixed bag, really
+        with hetero_batch_from_problems(probs) as b:
+            b.step(max(p.nt for p in probs) - 1)
+            st = b.status()
+            h, Q = b.history_arrays(0, b.L)
+            its = b.iterations(0, b.L)
+        for r, ((_, fx, m), p) in enumerate(zip(members, probs)):
+            if p.nt == b.L:
+                assert st[r] == 0, (label(members[r]), st[r])
+            compare(h[:p.nt, r, :p.N], Q[:p.nt, r, :p.N], its[:p.nt, r], fx, m)
+
+
 GEO = ("z_bed", "b_main", "m_main", "n_main", "n_left", "n_right", "is_compound", "h_bf", "b_fp_l", "b_fp_r", "m_fp", "curvature")
 
 
