@@ -33,6 +33,7 @@ FS_LIST_TRAP(FS_DECLARE, double, FS_F64) FS_LIST_TRAP(FS_DECLARE, float, FS_F32)
 FS_LIST_TABLE(FS_DECLARE, double, FS_F64) FS_LIST_TABLE(FS_DECLARE, float, FS_F32)
 FS_LIST_IRREGULAR(FS_DECLARE)
 FS_LIST_NODIAG(FS_DECLARE_NODIAG)
+FS_LIST_LONG(FS_DECLARE_LONG)
 #endif
 
 namespace {
@@ -70,13 +71,16 @@ typedef const void *KernelPtr;
 // full   == 1: no per-row selects, valid only for N = 64*W*M
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
-struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; };   // diag == 0: no history / trace stores
+struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int longk; };   // diag == 0: no history / trace stores; longk: fs_long.hpp
 #define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
   { DT, SEC, M, W, FULL, (int)(BCK), 1, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,          \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)> },
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>, 0 },
+#define FS_TABLE_ROW_LONG(R, DT, SEC, M, W, BCK)                                                \
+  { DT, SEC, M, W, 0, (int)(BCK), 1, &fs_launch_long<R, SEC, M, W, (int)(BCK)>,                  \
+    (KernelPtr)&fs::preissmann_long_kernel<R, SEC, M, W, (int)(BCK)>, 1 },
 #define FS_TABLE_ROW_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                       \
   { DT, SEC, M, W, FULL, (int)(BCK), 0, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>,    \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false> },
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false>, 0 },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -106,12 +110,13 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
                           FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER))
                           FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
-                          FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)};
+                          FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)
+                          FS_TABLE_ROW_LONG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0)};
 #else
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
-                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG)};
+                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG) FS_LIST_LONG(FS_TABLE_ROW_LONG)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
@@ -126,8 +131,10 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
   if (e.dtype != dtype || e.sec != sec) return false;
-  const int cap = 64 * e.W * e.M;       // rows of the scalar system: N - 1 cells + the downstream boundary row
+  // rows of the scalar system: N - 1 cells + the downstream boundary row; a long-reach kernel makes up to 64 / W passes
+  const long cap = 64L * e.W * e.M * (e.longk ? 64 / e.W : 1);
   if (cap < N) return false;
+  if (e.longk && (need_any || (e.bck == 0 && beyond0))) return false;      // no iteration budget there; class 0: closed-form kinds
   if (e.full && N != cap) return false;
   if (!e.diag && need_diag) return false;
   if (need_any && e.bck != -1) return false;
@@ -158,11 +165,16 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
     auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
+    if (best && e.longk != best->longk) {      // a kernel that keeps the reach on chip whenever one fits
+      if (!e.longk) best = &e;
+      continue;
+    }
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
         (e.M == best->M && e.W == best->W && spec > bspec))
       best = &e;
   }
-  if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..4096 nodes)";
+  if (!best && why) *why = "no kernel instantiation for N=" + std::to_string(N) + " (supported: 2..32768 nodes for the uniform section "
+                           "modes, 2..16384 for tables and polylines)";
   return best;
 }
 
@@ -201,6 +213,9 @@ struct fs_batch {
   void *derived[8] = {nullptr};        // device results of the last derive call, kept and reused
   size_t derived_cap[8] = {0};         // their capacities in elements
   unsigned long long *dbg = nullptr;
+  void *kc_scratch = nullptr;          // long reaches: level constants [B][4][passes * 64 W M]
+  size_t kc_scratch_elems = 0;
+  int passes = 0;
 };
 
 namespace {
@@ -284,6 +299,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.Yprev = (R *)b->Yprev; a.stage_hist = (R *)b->stage_hist; a.trace = (R *)b->trace; a.hydro = (R *)b->hydro; a.iters = b->iters; a.status = b->status;
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
   a.dbg = b->dbg;
+  a.kc_scratch = (R *)b->kc_scratch; a.passes = b->passes;
   a.iter_budget = 0; a.it_done = b->it_done;
 }
 
@@ -299,6 +315,17 @@ int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
     return fail("fs_batch_step: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
   if (!k) return fail("fs_batch_step: no kernel instantiation for this boundary kind at this size");
   b->kern = k;
+  b->passes = 0;
+  if (k->longk) {      // a reach longer than one lane grid: passes of 64 W M rows, level constants in a scratch of the batch's own
+    const size_t chunk = (size_t)64 * k->W * k->M;
+    b->passes = (int)((b->d.n_nodes + chunk - 1) / chunk);
+    const size_t need = (size_t)b->d.n_reaches * 4 * b->passes * chunk;
+    if (b->kc_scratch_elems < need) {
+      if (b->kc_scratch) { (void)hipFree(b->kc_scratch); b->kc_scratch = nullptr; b->kc_scratch_elems = 0; }
+      HIP_TRY(hipMalloc(&b->kc_scratch, need * b->esz));
+      b->kc_scratch_elems = need;
+    }
+  }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   if (b->d.dtype == FS_F64) {
     fs::KernelArgs<double> a; fill_args(b, n_steps, a);
@@ -408,7 +435,7 @@ void fs_batch_destroy(fs_batch *b) {
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
-                  b->reach_scheme, b->reach_kinds};
+                  b->reach_scheme, b->reach_kinds, b->kc_scratch};
   for (void *p : bufs) if (p) (void)hipFree(p);
   for (void *p : b->derived) if (p) (void)hipFree(p);
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -998,7 +1025,7 @@ int32_t fs_kernel_table_size(void) { return kNumEntries; }
 int fs_kernel_table_entry(int32_t i, int32_t *out) {
   if (i < 0 || i >= kNumEntries || !out) return fail("fs_kernel_table_entry: index out of range");
   const Entry &e = kEntries[i];
-  out[0] = e.dtype; out[1] = e.sec; out[2] = e.M; out[3] = e.W; out[4] = e.full; out[5] = e.bck; out[6] = e.diag; out[7] = 0;
+  out[0] = e.dtype; out[1] = e.sec; out[2] = e.M; out[3] = e.W; out[4] = e.full; out[5] = e.bck; out[6] = e.diag; out[7] = e.longk;
   return 0;
 }
 

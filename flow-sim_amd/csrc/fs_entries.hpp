@@ -18,6 +18,28 @@ void fs_launch(const void *args, int B, hipStream_t st) {
   hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
+template <typename R, int SEC, int M, int W, int BCK>
+void fs_launch_long(const void *args, int B, hipStream_t st) {
+  const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
+  hipLaunchKernelGGL((fs::preissmann_long_kernel<R, SEC, M, W, BCK>), dim3(B), dim3(64 * W), 0, st, a);
+}
+
+// reaches longer than one lane grid (fs_long.hpp): X(R, DT, SEC, M, W, BCK); capacity 64 M rows per wave slot x 64 slots
+#define FS_LIST_LONG(X) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0) \
+  X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 4, 0) \
+  X(double, FS_F64, FS_SEC_TABLE, 4, 4, -1) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 4, 4, -1) \
+  X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 4, 0) \
+  X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 4, 0) \
+  X(float, FS_F32, FS_SEC_TABLE, 4, 4, -1)
+#define FS_INSTANTIATE_LONG(R, DT, SEC, M, W, BCK)                                                       \
+  template __global__ void fs::preissmann_long_kernel<R, SEC, M, W, (int)(BCK)>(const fs::KernelArgs<R>); \
+  template void fs_launch_long<R, SEC, M, W, (int)(BCK)>(const void *, int, hipStream_t);
+#define FS_DECLARE_LONG(R, DT, SEC, M, W, BCK)                                                                  \
+  extern template __global__ void fs::preissmann_long_kernel<R, SEC, M, W, (int)(BCK)>(const fs::KernelArgs<R>); \
+  extern template void fs_launch_long<R, SEC, M, W, (int)(BCK)>(const void *, int, hipStream_t);
+
 #define FS_LIST_RECT(X, R, DT) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 2, 1, 0, 0) \
   X(R, DT, FS_SEC_RECT_UNIFORM, 4, 1, 0, 0) \

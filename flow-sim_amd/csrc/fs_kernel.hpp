@@ -173,6 +173,8 @@ template <typename R> struct KernelArgs {
   int32_t *status;         // [B]
   R *hist_h, *hist_Q;      // [levels][B][N] or nullptr
   R *trace;                // [levels][FS_TRACE_CAP][B] residual norms or nullptr
+  R *kc_scratch;           // long reaches (fs_long.hpp): [B][4][passes * 64 W M] level constants, owned by the batch
+  int32_t passes;          // long reaches: passes of 64 W M rows a workgroup makes over its reach
   unsigned long long *dbg; // diagnostic builds (-DFS_STAMP): [B][16][12] cycle sums per phase, else nullptr
 };
 
@@ -1240,3 +1242,5 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
 }
 
 }  // namespace fs
+
+#include "fs_long.hpp"

@@ -1,0 +1,425 @@
+// fs_long.hpp - the step kernel for reaches longer than one lane grid (N > 64 W M rows).
+//
+// The reference has no limit on the number of nodes (solver.py:34-38, :53-55: round(L / dx) + 1); preissmann_step_kernel has
+// one because a reach's unknowns live in the registers of one workgroup and its level constants in that workgroup's LDS
+// (4 096 rows: 128 KB).  Here a workgroup walks its reach in P passes of C = 64 W M rows each, and what the short kernel
+// keeps on chip lives in memory the workgroup owns, read and written through L2 / the Infinity Cache:
+//
+//   * the Newton vector itself stays in hg / Qg ([B][N], node-major) - loaded at the start of a pass, stored at its end;
+//   * the four level constants per cell go to a per-reach scratch ([4][P C], lane-minor within a pass like the LDS layout of
+//     the short kernel: consecutive lanes read consecutive doubles);
+//   * a Newton iteration makes two sweeps over the passes with the SAME code (one loop body, so both sweeps execute the
+//     same instructions and produce the same bits):
+//       sweep 0: fold + in-wave tree of every pass -> one segment per (pass, wave), at most 64 in all;
+//       then wave 0 reduces those segments with one more DPP tree (identity segments pad the 64 lanes), closes the root with
+//                the upstream boundary row and sends (p of the first row, m of the last row, m of the two shared nodes) of
+//                every (pass, wave) back through LDS;
+//       sweep 1: fold + in-wave tree again (their records are recomputed rather than stored: 2 KB of LDS per wave instead of
+//                128 KB for 64 sub-trees), way down, back-substitution, acceptance, update, store.
+//     The price is a second fold per iteration and ~130 B of L2 traffic per node and iteration - far from any HBM bound
+//     (state and scratch of the reaches in flight, 256 x 1 MB at 16 384 nodes, sit in the Infinity Cache).
+//
+// Same arithmetic as the short kernel (same node terms, rows, merges), general form only: ragged node counts, boundary kinds
+// switched at run time (class 0 for the uniform section modes, -1 - incl. the general storage row - for tables and polylines),
+// diagnostics compiled in (history, residual trace, conditioning monitor).  No iteration budget: host-evaluated boundary rows
+// (fs_batch_iterate) stay with the short kernels.
+#pragma once
+
+namespace fs {
+
+template <typename R, int W> struct SmemLong {
+  R tree[W][4][64];        // in-wave tree records of the pass being worked on
+  R xtree[4][64];          // records of the top tree over the (pass, wave) segments (wave 0)
+  R xseg[64][8];           // one segment per (pass, wave)
+  R xres[64][4];           // per (pass, wave): p of its first row, m of its last row, m of its first row, m of the next one's first row
+  R xbc[4];                // upstream boundary row on (p_0, m_0)
+  R bcp[2][FS_BC_MAX_PARAMS];
+  R xnorm[W];
+  R xtot;
+  int32_t xg[64];
+  int32_t xflag, xwarn;
+};
+
+template <typename R, int SEC, int M, int W, int BCK>
+__global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const KernelArgs<R> a) {
+  static_assert(BCK == 0 || BCK == -1, "long reaches: run-time boundary kinds only");
+  constexpr int T = 64 * W, C = T * M;
+  using Geo = Geometry<R, SEC>;
+  __shared__ SmemLong<R, W> sm;
+
+  const int reach = blockIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int NS = a.N;
+  const int N = a.reach_nodes ? a.reach_nodes[reach] : a.N, NC = N - 1;
+  const int P = a.passes;                                     // P C >= N rows, P W <= 64 segments
+  const size_t RP = (size_t)P * C;
+  R *const kcg = a.kc_scratch + (size_t)reach * 4 * RP;
+  const size_t base = (size_t)reach * NS;
+  // the row N-1 (downstream boundary row) and the node N-1: pass, lane, local index
+  const int pD = NC / C, tD = (NC - pD * C) / M, jD = NC - pD * C - tD * M;
+
+  Geo geo;
+  geo.init(a, reach, N);
+  const bool own_scheme = a.reach_scheme != nullptr;
+  const R th = own_scheme ? a.reach_scheme[reach] : a.theta, dt = own_scheme ? a.reach_scheme[(size_t)a.B + reach] : a.dt;
+  const R dx_ = own_scheme ? a.reach_scheme[(size_t)2 * a.B + reach] : a.dx;
+  const R r2dt = R(1) / (R(2) * dt), cq = th / dx_, cqk = (R(1) - th) / dx_, hth = R(0.5) * th, hthk = R(0.5) * (R(1) - th);
+  const R g = R(kG), i2c = R(0.5) / cq, kap = r2dt * i2c, dtcq = dt * cq, hx = hth * i2c, ghth = g * hth, ghthk = g * hthk, ghdt = g * hth * dt;
+
+  BCDesc<R> usd = a.us, dsd = a.ds;
+  if (a.reach_kinds) { usd.kind = a.reach_kinds[reach]; dsd.kind = a.reach_kinds[(size_t)a.B + reach]; }
+  if (t < 2 * FS_BC_MAX_PARAMS) {
+    const int side = t / FS_BC_MAX_PARAMS, i = t - side * FS_BC_MAX_PARAMS;
+    BCDesc<R> src = side ? a.ds : a.us;
+    src.kind = side ? dsd.kind : usd.kind;
+    static constexpr int kCount[] = {0, 1, 1, 2, 4, 5, 10, 5};
+    if (src.kind <= FS_BC_STORAGE && i < kCount[src.kind]) sm.bcp[side][i] = bc_param(src, i, reach, a.B);
+    if (src.kind == FS_BC_NORMAL_DEPTH && i == 2) {
+      const R S0 = bc_param(src, 0, reach, a.B);
+      sm.bcp[side][2] = (S0 < R(0) ? R(-1) : R(1)) * sqrt_(fabs_(S0));
+    }
+  }
+  if (usd.kind <= FS_BC_STORAGE) { usd.params = &sm.bcp[0][0]; usd.stride = 0; }
+  if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
+  const bool ds_storage = bc_is_storage(dsd.kind);
+  const bool isD = t == tD;                                   // (in pass pD) the lane of node N-1
+  R Yprev = ds_storage ? a.Yprev[reach] : R(0);
+  R QoldD = R(0);
+  int status = a.status[reach];
+  bool warn = status == FS_ILL_CONDITIONED;
+  if (warn) status = FS_OK;
+  if (t == 0) { sm.xflag = 0; sm.xwarn = 0; }
+
+  // nodes g0 .. g0 + M of a pass's lane (clamped copies beyond the last node)
+  auto load_nodes = [&](const R *hs, const R *Qs, int g0, R(&h)[M + 1], R(&Q)[M + 1]) {
+#pragma unroll
+    for (int j = 0; j <= M; ++j) {
+      const int node = min(g0 + j, N - 1);
+      h[j] = hs[base + node]; Q[j] = Qs[base + node];
+    }
+  };
+  auto kc_at = [&](int i, int p, int c) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
+  auto write_level_constants = [&](int p, int g0, const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+    NodeTerms<R> L = geo.terms(min(g0, N - 1), hh[0], QQ[0]);
+#pragma unroll
+    for (int c = 0; c < M; ++c) {
+      const NodeTerms<R> Rn = geo.terms(min(g0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
+      const R sumA = L.A + Rn.A;
+      kc_at(0, p, c) = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
+      kc_at(1, p, c) = fma_(cqk, fma_(QQ[c + 1], Rn.v, -(QQ[c] * L.v)), -((QQ[c + 1] + QQ[c]) * r2dt));
+      kc_at(2, p, c) = ghthk * sumA;
+      kc_at(3, p, c) = fma_(cqk, geo.bed_step(g0 + c) + (hh[c + 1] - hh[c]), hthk * (L.Se + Rn.Se));
+      L = Rn;
+    }
+  };
+
+  // ---- level constants of the entry level from the accepted state ----
+  for (int p = 0; p < P; ++p) {
+    const int g0 = p * C + t * M;
+    if (p * C > NC) break;
+    R hk[M + 1], Qk[M + 1];
+    load_nodes(a.hk, a.Qk, g0, hk, Qk);
+    if (p == pD && isD) {
+#pragma unroll
+      for (int j = 0; j < M; ++j) if (j == jD) QoldD = Qk[j];
+    }
+    write_level_constants(p, g0, hk, Qk);
+  }
+  __syncthreads();
+
+  for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
+    const int level = a.level0 + step + 1;
+    if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
+    if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
+    int it = 0;
+    bool converged = false;
+    R Ynew = Yprev;
+    while (!converged && status == FS_OK) {
+      ++it;
+      if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }
+      R nrm2 = R(0);
+      for (int phase = 0; phase < 2; ++phase) {
+        for (int p = 0; p < P; ++p) {
+          const int g0 = p * C + t * M;                                  // first row / node of this lane in this pass
+          if (p * C > NC) {                                              // nothing but padding: identity segments
+            if (phase == 0 && lane == 63) {
+              R *q = sm.xseg[p * W + wave];
+              q[0] = R(0); q[1] = R(0); q[2] = R(0); q[3] = R(0); q[4] = R(1); q[5] = R(0); q[6] = R(0); q[7] = R(0);
+              sm.xg[p * W + wave] = 0;
+            }
+            continue;
+          }
+          R h[M + 1], Q[M + 1];
+          load_nodes(a.hg, a.Qg, g0, h, Q);
+          if (phase == 1) __syncthreads();          // every lane holds its nodes before any lane stores updated ones
+
+          // ---- boundary rows (boundary.py:56-242) ----
+          BCRow<R> Urow, Drow;
+          Urow.dh = R(1); Urow.dq = R(0); Urow.res = R(0);
+          Drow.dh = R(1); Drow.dq = R(0); Drow.res = R(0);
+          if (p == 0 && t == 0) {
+            R dummy; int flag = 0;
+            Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
+            if (phase == 0) nrm2 += Urow.res * Urow.res;
+          }
+          if (p == pD && isD) {
+            R hD = h[0], QD = Q[0];
+            int flag = 0;
+#pragma unroll
+            for (int j = 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
+            Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
+            if (phase == 0) nrm2 += Drow.res * Drow.res;
+            if (flag) sm.xflag = flag;
+          }
+
+          // ---- local assembly + fold (the short kernel's, ragged form) ----
+          LocalElim<R> el[M - 1];
+          R iTn[M + 1];
+          Seg<R> seg;
+          seg.u1 = R(0); seg.u3 = R(-1); seg.ru = R(0);
+          R rcLast;
+          {
+            NodeTerms<R> L = geo.terms(min(g0, N - 1), h[0], Q[0]);
+            R i2tL = dt * L.rT;
+            iTn[0] = i2tL;
+            if (p == 0 && t == 0 && phase == 0) {
+              const R x = Urow.dh * i2tL, y = Urow.dq * i2c;
+              sm.xbc[0] = x + y; sm.xbc[1] = x - y; sm.xbc[2] = -Urow.res;
+            }
+            R rcPrev = R(0);
+#pragma unroll
+            for (int c = 0; c < M; ++c) {
+              const R k0 = kc_at(0, p, c), k1 = kc_at(1, p, c), k2 = kc_at(2, p, c), k3 = kc_at(3, p, c);
+              const NodeTerms<R> Rn = geo.terms(min(g0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+              const R i2tR = dt * Rn.rT;
+              iTn[c + 1] = i2tR;
+              Row<R> row;
+              {
+                const R sumA = L.A + Rn.A;
+                const R Cres = sumA * r2dt + cq * (Q[c + 1] - Q[c]) + k0;
+                const R gA = fma_(ghth, sumA, k2);
+                const R S = cq * (geo.bed_step(g0 + c) + (h[c + 1] - h[c])) + hth * (L.Se + Rn.Se) + k3;
+                const R Mres = (Q[c + 1] + Q[c]) * r2dt + cq * (Q[c + 1] * Rn.v - Q[c] * L.v) + k1 + gA * S;
+                const R gAdt = gA * dt, gAx = gA * hx, sdt = ghdt * S;
+                const R X0 = fma_(gAdt, fma_(hth, L.eAT, -(cq * L.rT)), fma_(dtcq, L.v * L.v, sdt));
+                const R X1 = fma_(gAdt, fma_(hth, Rn.eAT, cq * Rn.rT), fma_(-dtcq, Rn.v * Rn.v, sdt));
+                const R Y0 = fma_(gAx, L.eQ, kap - L.v);
+                const R Y1 = fma_(gAx, Rn.eQ, kap + Rn.v);
+                const R ga = X1 + Y1;
+                row.al = X0 + Y0; row.D = (X0 - Y0) - ga; row.de = X1 - Y1;
+                row.rho0 = fma_(ga, Cres, -Mres);
+                row.rc = -Cres;
+                R r2 = fma_(Cres, Cres, Mres * Mres);
+                const int k = g0 + c;
+                if (k >= NC) {                         // the downstream boundary row, then identity rows
+                  const bool bcr = k == NC;
+                  const R x = Drow.dh * i2tL, y = Drow.dq * i2c;
+                  row.al = bcr ? x + y : R(0); row.D = bcr ? x - y : R(1); row.de = R(0);
+                  row.rho0 = bcr ? -Drow.res : R(0); row.rc = R(0);
+                  r2 = R(0);
+                }
+                if (phase == 0) nrm2 += r2;
+              }
+              if (c == 0) {
+                seg.d1 = row.al; seg.d2 = row.D; seg.d3 = row.de; seg.rd = row.rho0;
+              } else {
+                const R r = frcp(seg.d2);
+                const R R1 = seg.d1 * r, R2 = seg.d3 * r, R3 = seg.rd * r;
+                LocalElim<R> &e = el[c - 1];
+                e.R1.put(R1); e.R2.put(R2); e.R3.put(R3); e.qc.put(rcPrev);
+                const R rho = fma_(-row.al, rcPrev, row.rho0);
+                seg.d1 = row.al * R1; seg.d2 = fma_(row.al, R2, row.D); seg.d3 = row.de; seg.rd = fma_(row.al, R3, rho);
+                seg.u1 = fma_(-seg.u3, R1, seg.u1); seg.ru = fma_(-seg.u3, R3, seg.ru); seg.u3 = -(seg.u3 * R2);
+              }
+              rcPrev = row.rc;
+              L = Rn; i2tL = i2tR;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            seg.rc = rcPrev; rcLast = rcPrev;
+          }
+          const R upU1 = seg.u1, upU3 = seg.u3, upRu = seg.ru;
+          int gi = hi_abs(seg.u3);
+
+          // ---- in-wave tree, up ----
+          auto up_level = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int d = 1 << l;
+            const Seg<R> left = seg_from_below<d>(seg);
+            Seg<R> mg; Elim<R> e;
+            merge(left, seg, mg, e);
+            if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+              R *q = &sm.tree[wave][0][(64 - (64 >> l)) + (lane >> (l + 1))];
+              q[0 * 64] = e.A1; q[1 * 64] = e.A2; q[2 * 64] = e.A3; q[3 * 64] = e.rc;
+            }
+            seg = mg;
+            gi = max_(max_(tree_from_below<d>(gi), gi), hi_abs(mg.u3));
+          };
+          up_level(std::integral_constant<int, 0>{}); up_level(std::integral_constant<int, 1>{});
+          up_level(std::integral_constant<int, 2>{}); up_level(std::integral_constant<int, 3>{});
+          up_level(std::integral_constant<int, 4>{}); up_level(std::integral_constant<int, 5>{});
+
+          if (phase == 0) {
+            if (lane == 63) {
+              R *q = sm.xseg[p * W + wave];
+              q[0] = seg.u1; q[1] = seg.u3; q[2] = seg.ru; q[3] = seg.d1; q[4] = seg.d2; q[5] = seg.d3; q[6] = seg.rd; q[7] = seg.rc;
+              sm.xg[p * W + wave] = gi;
+            }
+            continue;
+          }
+
+          // ---- sweep 1: way down, back-substitution, acceptance, update ----
+          // the records of this pass's tree were written by this wave's own lanes just above: LDS executes a wave's
+          // instructions in order, the fence keeps the compiler from hoisting the reads over the predicated stores
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const R *xr = sm.xres[p * W + wave];
+          R pL = xr[0], mR = xr[1];
+          auto down_level = [&](auto lc) {
+            constexpr int l = decltype(lc)::value;
+            const R *q = &sm.tree[wave][0][(64 - (64 >> l)) + (lane >> (l + 1))];
+            Elim<R> e;
+            e.A1 = q[0 * 64]; e.A2 = q[1 * 64]; e.A3 = q[2 * 64]; e.rc = q[3 * 64];
+            const R sep = separator(e, pL, mR);
+            const bool upper = ((lane >> l) & 1) != 0;
+            pL = upper ? e.rc - sep : pL;
+            mR = upper ? mR : sep;
+          };
+          down_level(std::integral_constant<int, 5>{}); down_level(std::integral_constant<int, 4>{});
+          down_level(std::integral_constant<int, 3>{}); down_level(std::integral_constant<int, 2>{});
+          down_level(std::integral_constant<int, 1>{}); down_level(std::integral_constant<int, 0>{});
+          R mA = fma_(-upU1, pL, fma_(-upU3, mR, upRu));
+          if (lane == 0) mA = xr[2];
+          R mB = dpp_mov<0x134>(mA);                // wave_rol:1
+          if (lane == 63) mB = xr[3];
+          R dh[M + 1], dQ[M + 1];
+          {
+            auto rc_of = [&](int j) { return j + 1 < M ? el[j].qc.get() : rcLast; };
+            R mj = mR;
+            {
+              const R pM = rcLast - mR;
+              dh[M] = (pM + mB) * iTn[M]; dQ[M] = (pM - mB) * i2c;
+            }
+#pragma unroll
+            for (int j = M - 1; j >= 1; --j) {
+              const R mprev = j == 1 ? mA : fma_(-el[j - 1].R2.get(), mj, fma_(-el[j - 1].R1.get(), pL, el[j - 1].R3.get()));
+              const R pj = rc_of(j - 1) - mprev;
+              dh[j] = (pj + mj) * iTn[j]; dQ[j] = (pj - mj) * i2c;
+              mj = mprev;
+            }
+            dh[0] = (pL + mA) * iTn[0]; dQ[0] = (pL - mA) * i2c;
+          }
+          if (converged) {                           // the pre-update iterate is the level's result
+            if (p == 0 && t == 0) {
+              a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
+              a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
+              a.iters[(size_t)level * a.B + reach] = it;
+            }
+            const bool last = step == a.n_steps - 1;
+            R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * NS + g0 : nullptr;
+            R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * NS + g0 : nullptr;
+#pragma unroll
+            for (int j = 0; j < M; ++j) {
+              if (g0 + j < N) {
+                if (last) { a.hk[base + g0 + j] = h[j]; a.Qk[base + g0 + j] = Q[j]; }
+                if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
+              }
+            }
+            if (p == pD && isD) {
+#pragma unroll
+              for (int j = 0; j < M; ++j)
+                if (j == jD) {
+                  a.hydro[((size_t)level * 4 + 2) * a.B + reach] = h[j];
+                  a.hydro[((size_t)level * 4 + 3) * a.B + reach] = Q[j];
+                  QoldD = Q[j];
+                }
+              Yprev = Ynew;
+              if (ds_storage) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
+            }
+            write_level_constants(p, g0, h, Q);
+          }
+#pragma unroll
+          for (int j = 0; j < M; ++j)
+            if (g0 + j < N) { a.hg[base + g0 + j] = h[j] + dh[j]; a.Qg[base + g0 + j] = Q[j] + dQ[j]; }
+        }   // passes
+
+        if (phase == 0) {
+          // ---- between the sweeps: the top tree over the (pass, wave) segments, by wave 0 ----
+          nrm2 = wave_sum(nrm2);
+          if (lane == 63) sm.xnorm[wave] = nrm2;
+          __syncthreads();
+          if (wave == 0) {
+            const int S = P * W;
+            const int sl = lane < S ? lane : 0;
+            const R *q = sm.xseg[sl];
+            Seg<R> xs;
+            xs.u1 = q[0]; xs.u3 = q[1]; xs.ru = q[2]; xs.d1 = q[3]; xs.d2 = q[4]; xs.d3 = q[5]; xs.rd = q[6]; xs.rc = q[7];
+            int gx = sm.xg[sl];
+            if (lane >= S) { xs.u1 = R(0); xs.u3 = R(0); xs.ru = R(0); xs.d1 = R(0); xs.d2 = R(1); xs.d3 = R(0); xs.rd = R(0); xs.rc = R(0); gx = 0; }
+            const R u1o = xs.u1, u3o = xs.u3, ruo = xs.ru;
+            auto xup = [&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              constexpr int d = 1 << l;
+              const Seg<R> left = seg_from_below<d>(xs);
+              Seg<R> mg; Elim<R> e;
+              merge(left, xs, mg, e);
+              if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+                R *w = &sm.xtree[0][(64 - (64 >> l)) + (lane >> (l + 1))];
+                w[0 * 64] = e.A1; w[1 * 64] = e.A2; w[2 * 64] = e.A3; w[3 * 64] = e.rc;
+              }
+              xs = mg;
+              gx = max_(max_(tree_from_below<d>(gx), gx), hi_abs(mg.u3));
+            };
+            xup(std::integral_constant<int, 0>{}); xup(std::integral_constant<int, 1>{}); xup(std::integral_constant<int, 2>{});
+            xup(std::integral_constant<int, 3>{}); xup(std::integral_constant<int, 4>{}); xup(std::integral_constant<int, 5>{});
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            R p0, m0, ml;
+            close_root(xs, sm.xbc[0], sm.xbc[1], sm.xbc[2], p0, m0, ml);        // valid in lane 63
+            R px = read_lane(p0, 63), mx = read_lane(ml, 63);
+            auto xdown = [&](auto lc) {
+              constexpr int l = decltype(lc)::value;
+              const R *w = &sm.xtree[0][(64 - (64 >> l)) + (lane >> (l + 1))];
+              Elim<R> e;
+              e.A1 = w[0 * 64]; e.A2 = w[1 * 64]; e.A3 = w[2 * 64]; e.rc = w[3 * 64];
+              const R sep = separator(e, px, mx);
+              const bool upper = ((lane >> l) & 1) != 0;
+              px = upper ? e.rc - sep : px;
+              mx = upper ? mx : sep;
+            };
+            xdown(std::integral_constant<int, 5>{}); xdown(std::integral_constant<int, 4>{}); xdown(std::integral_constant<int, 3>{});
+            xdown(std::integral_constant<int, 2>{}); xdown(std::integral_constant<int, 1>{}); xdown(std::integral_constant<int, 0>{});
+            const R ma = fma_(-u1o, px, fma_(-u3o, mx, ruo));
+            R mb = dpp_mov<0x134>(ma);              // wave_rol:1 : m of the next segment's first row
+            if (lane == 63) mb = R(0);
+            if (lane < S) { R *o = sm.xres[lane]; o[0] = px; o[1] = mx; o[2] = ma; o[3] = (lane == S - 1) ? R(0) : mb; }
+            R tot = R(0);
+#pragma unroll
+            for (int w = 0; w < W; ++w) tot += sm.xnorm[w];
+            // (read in uniform control flow: inside a branch only lane 0 takes, the compiler may compute gx for lane 0 alone)
+            const int gtop = __builtin_amdgcn_readlane(gx, 63);
+            if (lane == 0) {
+              sm.xtot = tot;
+              if (gtop > growth_limit_bits<R>()) sm.xwarn = 1;
+            }
+          }
+          __syncthreads();
+          const R tot = sm.xtot;
+          if (sm.xflag != 0) status = sm.xflag;
+          if (sm.xwarn != 0) warn = true;
+          if (!(tot <= finite_max<R>())) status = FS_NAN;
+          const R err = sqrt_(tot);
+          if (a.trace && t == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
+          converged = status == FS_OK && err < a.tol;
+        }
+      }   // sweeps
+      __syncthreads();                              // this iteration's stores before the next iteration's loads
+    }
+    if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
+  }
+  if (t == 0) a.status[reach] = (status == FS_OK && warn) ? (int)FS_ILL_CONDITIONED : status;
+  if (ds_storage && t == tD) a.Yprev[reach] = Yprev;
+}
+
+}  // namespace fs

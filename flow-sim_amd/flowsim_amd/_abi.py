@@ -128,7 +128,7 @@ def device_count():
     return lib().fs_device_count()
 
 
-KERNEL_FIELDS = ("dtype", "section_mode", "cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag", "reserved")
+KERNEL_FIELDS = ("dtype", "section_mode", "cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag", "long_reach")
 
 
 def kernel_table():

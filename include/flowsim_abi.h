@@ -136,7 +136,8 @@ enum {
 
 typedef struct fs_batch_desc {
   int32_t n_reaches;     /* B */
-  int32_t n_nodes;       /* N, 2..4096 */
+  int32_t n_nodes;       /* N >= 2; up to 4 096 (uniform section modes) / 2 048 (tables, polylines) a reach stays on chip, longer ones -
+                            to 32 768 / 16 384 nodes - run on the multi-pass kernel (state and level constants through L2) */
   int32_t dtype;         /* FS_F64 | FS_F32 */
   int32_t section_mode;  /* FS_SEC_* */
   int32_t device;        /* HIP device ordinal */
@@ -294,7 +295,8 @@ int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_
  * entry i described by out[8] = dtype, section_mode, cells per lane M, waves per reach W, full (1: only
  * N == 64*W*M: the downstream boundary row takes the last row of the lane grid), boundary class (-1 any kind, 0 any but FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW,
  * 1 closed-form rectangular rows, 2+k flow hydrograph upstream and kind k downstream), diag (0: compiled
- * without history / trace stores), one reserved slot (0).  The environment
+ * without history / trace stores), long (1: the multi-pass kernel for reaches longer than one lane grid: capacity 64*M rows per
+ * wave slot x 64 slots).  The environment
  * variable FS_KERNEL_INDEX=i makes fs_batch_step use entry i or fail if it does not fit the batch (tests:
  * every instantiation is checked against the oracle). fs_batch_kernel_index: the entry the last step used. */
 int32_t fs_kernel_table_size(void);

@@ -17,7 +17,7 @@ int main(void) {
     int32_t e[8];
     EXPECT(fs_kernel_table_entry(i, e) == 0);
     EXPECT((e[0] == FS_F64 || e[0] == FS_F32) && e[1] >= FS_SEC_RECT_UNIFORM && e[1] <= FS_SEC_IRREGULAR);
-    EXPECT(e[2] >= 2 && e[3] >= 1 && e[3] <= 8 && (e[4] == 0 || e[4] == 1) && e[5] >= -1 && (e[6] == 0 || e[6] == 1) && e[7] == 0);
+    EXPECT(e[2] >= 2 && e[3] >= 1 && e[3] <= 8 && (e[4] == 0 || e[4] == 1) && e[5] >= -1 && (e[6] == 0 || e[6] == 1) && (e[7] == 0 || e[7] == 1));
   }
   int32_t e[8];
   EXPECT(fs_kernel_table_entry(-1, e) < 0 && strlen(fs_last_error()) > 0);

@@ -39,11 +39,13 @@ TABLE = _table()
 def _id(e):
     sec = ("rect", "trap", "table", "irr")[e["section_mode"]]
     return (f"{e['index']:03d}-{'f64' if e['dtype'] == 0 else 'f32'}-{sec}-{e['cells_per_thread']}x{e['waves_per_reach']}"
-            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}")
+            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-long' if e.get('long_reach') else ''}")
 
 
 def _nodes(e):
     cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]      # rows of the scalar system: N - 1 cells + the boundary row
+    if e.get("long_reach"):
+        return 2 * cap + cap // 3 + e["index"] % 7            # the multi-pass kernel (fs_long.hpp): three passes, the last one ragged
     if e["full"]:
         return cap
     return max(2, cap - 1 - e["index"] % 5)          # ragged: 1..5 rows short of the capacity
@@ -141,6 +143,9 @@ def case_for(e):
         else:
             raise KeyError("no recipe: uniform-geometry kernels of class -1 do not exist")
         return prismatic_problem(e, pair, trap), ("trap_uniform" if trap else "rect_uniform"), None
+    if sec == A.SEC_TABLE and e.get("long_reach"):
+        # a long prismatic reach described as a table (the trapezoid-family code path of the multi-pass kernel, three passes)
+        return prismatic_problem(e, GENERAL_PAIRS[e["index"] % len(GENERAL_PAIRS)], e["index"] % 2 == 0), "table", None
     if sec == A.SEC_TABLE:
         if bck == -1:      # the class exists for the general reservoir row: three reference fixtures, by capacity
             name = ("storage_curve_poly_losses", "storage_curve_power_trap", "storage_curve_closed")[e["index"] % 3]
@@ -180,7 +185,7 @@ def test_instantiation_against_the_oracle(e, monkeypatch):
     f32 = e["dtype"] == A.F32
     if f32:
         p.tol = 1e-3 if p.N <= 600 else 2e-2      # fp32 cannot resolve ||R|| below ~6e-8 |Q| sqrt(2N) (bench.py uses the same)
-    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]
+    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"] * (64 // e["waves_per_reach"] if e.get("long_reach") else 1)
     assert p.N <= cap, "recipe does not fit the entry"
     ref = oracle_run(p)
     assert ref["status"] == 0

@@ -234,7 +234,7 @@ def test_api_misuse_is_reported_not_computed():
     from flowsim_amd import _abi as A
     import ctypes as C
     E = A.FlowsimError
-    for bad in ((0, 30, 5), (1, 1, 5), (1, 30, 1), (1, 5000, 5)):
+    for bad in ((0, 30, 5), (1, 1, 5), (1, 30, 1), (1, 40000, 5)):        # (reaches beyond 32 768 nodes: no kernel, not even the multi-pass one)
         with pytest.raises(E, match="n_reaches >= 1|no kernel instantiation"):
             PreissmannBatch(*bad)
     with PreissmannBatch(2, 40, 6) as b:
@@ -365,6 +365,79 @@ def test_ragged_node_counts_against_the_c_oracle(N):
         assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL, N
         assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL, N
         assert np.array_equal(its[:, i], out["iters"]), N
+
+
+@pytest.mark.parametrize("N", [4097, 6000, 8192, 16384, 32768])
+@pytest.mark.parametrize("mode", ["rect_uniform", "table", "trap_uniform"])
+def test_reaches_longer_than_the_lane_grid_against_the_c_oracle(N, mode):
+    """The reference has no limit on the number of nodes (solver.py:34-38, :53-55).  Beyond what one workgroup keeps on chip
+    (4 096 rows for the uniform section modes, 2 048 for tables) the multi-pass kernel of fs_long.hpp takes over: state in
+    HBM / L2, level constants in a scratch of the batch, two sweeps per Newton iteration.  Same bar as everywhere: the pivoted C
+    oracle to 1e-8 with identical Newton counts; three reaches per batch, chunked stepping equal to one launch bit for bit."""
+    from fixture_batch import batch_from_problems, hetero_batch_from_problems
+    from oracle import c_oracle
+    from synth import rect_problem
+    if mode != "rect_uniform" and N > 16384:
+        pytest.skip("tables stop at 16 384 nodes")
+    probs = [rect_problem(N, seed=900 + N % 97 + s, n_steps=3) for s in range(3)]
+    if mode == "trap_uniform":
+        for p in probs:
+            p.geo["m_main"][:] = 1.5
+            # (the rectangle's normal depth is not the trapezoid's: the run starts with a small adjustment wave - fine)
+    # (a table is shared by a batch unless every reach brings its own: the three channels differ, so they do)
+    with (hetero_batch_from_problems(probs) if mode == "table" else batch_from_problems(probs, mode=mode)) as b:
+        b.step(3)
+        assert np.all(b.status() == 0)
+        info = b.kernel_info()
+        assert 64 * info["cells_per_thread"] * info["waves_per_reach"] < N         # the multi-pass kernel did run
+        h, Q = b.history_arrays()
+        its = b.iterations()
+        hyd = b.hydrographs()
+    for i, p in enumerate(probs):
+        out = c_oracle.run(p)
+        assert rel_err(h[:, i], out["depth"], 1e-3) <= TOL, (N, mode)
+        assert rel_err(Q[:, i], out["flow"], 1.0) <= TOL, (N, mode)
+        assert np.array_equal(its[:, i], out["iters"]), (N, mode)
+    with batch_from_problems(probs[1:2], mode=mode, history=False) as c:          # one reach alone, stepped level by level
+        for _ in range(3):
+            c.step(1)
+        assert np.array_equal(c.hydrographs()[:, :, 0], hyd[:, :, 1])
+
+
+def test_gerd_roseires_at_a_spatial_step_of_25_m():
+    """cases/gerd_roseires refined to dx = 25 m: 4 817 nodes of compound sections with curvature and the gate curve - more than
+    a table kernel keeps on chip; against the C oracle over the first levels"""
+    from cases.gerd_roseires.model import build as build_gerd
+    from fixture_batch import batch_from_problems
+    from flowsim_amd.hydromodel.preissmann import boundary_to_spec
+    from oracle import c_oracle
+    solver, _ = build_gerd(inflow_hyd_func=None, sim_duration=4 * 3600, spatial_step=25)
+    ch = solver.channel
+    N = solver.number_of_nodes
+    assert N > 4096
+    nt = 4
+    from flowsim_amd import PreissmannBatch, _abi as A
+    us, ds = boundary_to_spec(ch.upstream_boundary, nt, solver.time_step), boundary_to_spec(ch.downstream_boundary, nt, solver.time_step)
+    with PreissmannBatch(1, N, nt, section_mode="table", history=True) as b:
+        b.set_scheme(solver.theta, solver.time_step, solver.spatial_step, 1e-6, 100)
+        b.set_geometry_table(ch.node_geometry)
+        b.set_boundary(A.UPSTREAM, us); b.set_boundary(A.DOWNSTREAM, ds)
+        b.set_state(ch.initial_conditions[:, 0], ch.initial_conditions[:, 1])
+        b.step(nt - 1)
+        assert b.status()[0] == 0
+        h, Q = b.history_arrays(0, nt)
+        its = b.iterations(0, nt)[:, 0]
+    geo = {k: np.asarray(ch.node_geometry[k], dtype=np.float64) for k in O.GEO_KEYS}
+    p = O.Problem(geo=geo, h0=ch.initial_conditions[:, 0].copy(), Q0=ch.initial_conditions[:, 1].copy(),
+                  us=O.BC("flow_hydrograph", bed_level=float(geo["z_bed"][0]), target=np.asarray(us.target, dtype=np.float64)[:nt]),
+                  ds=O.BC("rating_curve", bed_level=float(ds.params["bed_level"]), rc_type="blend",
+                          rc=dict(initial_stage=ds.params["stage0"], buffer=ds.params["buffer"], dY=ds.params["dY"],
+                                  low=[ds.params["lo0"], ds.params["lo1"], ds.params["lo2"]], high=[ds.params["hi0"], ds.params["hi1"], ds.params["hi2"]])),
+                  theta=solver.theta, dt=float(solver.time_step), dx=float(solver.spatial_step), nt=nt, tol=1e-6)
+    out = c_oracle.run(p)
+    assert out["status"] == 0
+    assert rel_err(h[:, 0], out["depth"], 1e-3) <= TOL and rel_err(Q[:, 0], out["flow"], 1.0) <= TOL
+    assert np.array_equal(its, out["iters"])
 
 
 def test_failing_reach_does_not_disturb_its_neighbours():
