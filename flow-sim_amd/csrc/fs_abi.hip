@@ -7,11 +7,16 @@
 // that needs one fails and says so.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fs_entries.hpp"
@@ -180,6 +185,100 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------
+// Host <-> device staging.  Large transfers go through a ring of pinned chunks (hipHostMalloc): while the DMA engine moves
+// chunk i, a few host threads copy (and, for fp32 batches, convert) chunk i + 1 between the caller's pageable buffer and
+// the next pinned chunk - the host copy, the page faults of a freshly allocated destination and the PCIe transfer overlap
+// instead of adding up.  (A pageable hipMemcpy device -> host measured 22.9 GB/s on this box, profiles/round2/pcie.json.)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+class CopyPool {                       // a handful of persistent host threads: parallel_for over slices of a chunk
+ public:
+  static CopyPool &get() { static CopyPool p; return p; }
+  int size() const { return (int)workers_.size() + 1; }
+  void run(size_t n, const std::function<void(size_t, size_t)> &fn) {        // fn(begin, end) over [0, n)
+    const int parts = size();
+    if (n < (size_t)1 << 16 || parts == 1) { fn(0, n); return; }
+    std::lock_guard<std::mutex> one_at_a_time(run_m_);        // handles on different host threads share the pool
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      fn_ = &fn; n_ = n; parts_ = parts; pending_ = parts - 1; ++epoch_;
+    }
+    cv_.notify_all();
+    slice(parts - 1);
+    std::unique_lock<std::mutex> lk(m_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+  }
+
+ private:
+  CopyPool() {
+    const char *env = std::getenv("FS_COPY_THREADS");
+    int want = env ? std::atoi(env) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency() / 2));
+    want = std::max(1, std::min(want, 32));
+    for (int i = 0; i + 1 < want; ++i) workers_.emplace_back([this, i] { loop(i); });
+  }
+  ~CopyPool() {
+    { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++epoch_; }
+    cv_.notify_all();
+    for (auto &t : workers_) t.join();
+  }
+  void slice(int part) {
+    const size_t per = (n_ + parts_ - 1) / parts_, a = std::min(n_, per * part), b = std::min(n_, a + per);
+    if (a < b) (*fn_)(a, b);
+  }
+  void loop(int id) {
+    unsigned long seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&] { return epoch_ != seen; });
+      seen = epoch_;
+      if (stop_) return;
+      lk.unlock();
+      slice(id);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex m_, run_m_;
+  std::condition_variable cv_, done_;
+  const std::function<void(size_t, size_t)> *fn_ = nullptr;
+  size_t n_ = 0;
+  int parts_ = 1, pending_ = 0;
+  unsigned long epoch_ = 0;
+  bool stop_ = false;
+};
+
+constexpr size_t kStageChunk = (size_t)32 << 20;      // bytes per pinned chunk
+constexpr int kStageSlots = 3;
+constexpr size_t kStageMin = (size_t)8 << 20;         // smaller transfers: one plain copy
+
+struct Staging {
+  void *buf[kStageSlots] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev[kStageSlots] = {nullptr, nullptr, nullptr};
+  bool ready = false;
+  int init() {
+    if (ready) return 0;
+    for (int i = 0; i < kStageSlots; ++i) {
+      if (hipHostMalloc(&buf[i], kStageChunk, hipHostMallocDefault) != hipSuccess) return -1;
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+    }
+    ready = true;
+    return 0;
+  }
+  void release() {
+    for (int i = 0; i < kStageSlots; ++i) {
+      if (buf[i]) (void)hipHostFree(buf[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+      buf[i] = nullptr; ev[i] = nullptr;
+    }
+    ready = false;
+  }
+};
+
+}  // namespace
+
 struct fs_batch {
   fs_batch_desc d;
   size_t esz;                 // sizeof(real)
@@ -213,6 +312,7 @@ struct fs_batch {
   void *derived[8] = {nullptr};        // device results of the last derive call, kept and reused
   size_t derived_cap[8] = {0};         // their capacities in elements
   unsigned long long *dbg = nullptr;
+  Staging stage;                       // pinned chunks for large host <-> device transfers
   void *kc_scratch = nullptr;          // long reaches: level constants [B][4][passes * 64 W M]
   size_t kc_scratch_elems = 0;
   int passes = 0;
@@ -223,27 +323,74 @@ namespace {
 int upload(fs_batch *b, void **dst, const double *src, size_t n) {
   TraceRange range_("flowsim:upload");
   if (!*dst) HIP_TRY(hipMalloc(dst, n * b->esz));
-  if (b->d.dtype == FS_F64) {
-    HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-  } else {
-    std::vector<float> tmp(n);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
-    HIP_TRY(hipMemcpyAsync(*dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+  const bool f64 = b->d.dtype == FS_F64;
+  if (f64 || n * b->esz < kStageMin || b->stage.init() != 0) {
+    // fp64: the runtime's own pageable path (it pins and pipelines; ~55 GB/s here); small fp32 arrays: convert, then one copy
+    if (f64) {
+      HIP_TRY(hipMemcpyAsync(*dst, src, n * sizeof(double), hipMemcpyHostToDevice, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+    } else {
+      std::vector<float> tmp(n);
+      for (size_t i = 0; i < n; ++i) tmp[i] = (float)src[i];
+      HIP_TRY(hipMemcpyAsync(*dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+      HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    return 0;
   }
+  // fp32, large: convert chunk i + 1 into a pinned slot (host threads) while chunk i is on the bus
+  const size_t per = kStageChunk / sizeof(float);
+  int slot = 0;
+  for (size_t off = 0; off < n; off += per, slot = (slot + 1) % kStageSlots) {
+    const size_t cnt = std::min(per, n - off);
+    HIP_TRY(hipEventSynchronize(b->stage.ev[slot]));              // the DMA that last read this slot is through
+    float *pin = (float *)b->stage.buf[slot];
+    const double *sp = src + off;
+    CopyPool::get().run(cnt, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) pin[i] = (float)sp[i]; });
+    HIP_TRY(hipMemcpyAsync((char *)*dst + off * sizeof(float), pin, cnt * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipEventRecord(b->stage.ev[slot], b->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return 0;
 }
 
 int download(fs_batch *b, double *dst, const void *src, size_t off_elems, size_t n) {
   TraceRange range_("flowsim:download");
   HIP_TRY(hipStreamSynchronize(b->stream));
-  if (b->d.dtype == FS_F64) {
-    HIP_TRY(hipMemcpy(dst, (const char *)src + off_elems * 8, n * 8, hipMemcpyDeviceToHost));
-  } else {
-    std::vector<float> tmp(n);
-    HIP_TRY(hipMemcpy(tmp.data(), (const char *)src + off_elems * 4, n * 4, hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+  const bool f64 = b->d.dtype == FS_F64;
+  const char *dev = (const char *)src + off_elems * b->esz;
+  if (n * b->esz < kStageMin || b->stage.init() != 0) {
+    if (f64) {
+      HIP_TRY(hipMemcpy(dst, dev, n * 8, hipMemcpyDeviceToHost));
+    } else {
+      std::vector<float> tmp(n);
+      HIP_TRY(hipMemcpy(tmp.data(), dev, n * 4, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < n; ++i) dst[i] = tmp[i];
+    }
+    return 0;
+  }
+  // chunk i + 1 comes over the bus into a pinned slot while host threads copy (fp32: widen) chunk i into the caller's buffer
+  const size_t per = kStageChunk / b->esz, chunks = (n + per - 1) / per;
+  auto issue = [&](size_t c) -> hipError_t {
+    const int slot = (int)(c % kStageSlots);
+    const size_t off = c * per, cnt = std::min(per, n - off);
+    hipError_t e = hipMemcpyAsync(b->stage.buf[slot], dev + off * b->esz, cnt * b->esz, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipEventRecord(b->stage.ev[slot], b->stream);
+    return e;
+  };
+  for (size_t c = 0; c < std::min<size_t>(chunks, kStageSlots - 1); ++c) HIP_TRY(issue(c));
+  for (size_t c = 0; c < chunks; ++c) {
+    const int slot = (int)(c % kStageSlots);
+    const size_t off = c * per, cnt = std::min(per, n - off);
+    if (c + kStageSlots - 1 < chunks) HIP_TRY(issue(c + kStageSlots - 1));   // its slot was drained in the iteration before
+    HIP_TRY(hipEventSynchronize(b->stage.ev[slot]));
+    double *dp = dst + off;
+    if (f64) {
+      const double *pin = (const double *)b->stage.buf[slot];
+      CopyPool::get().run(cnt, [&](size_t lo, size_t hi) { std::memcpy(dp + lo, pin + lo, (hi - lo) * sizeof(double)); });
+    } else {
+      const float *pin = (const float *)b->stage.buf[slot];
+      CopyPool::get().run(cnt, [&](size_t lo, size_t hi) { for (size_t i = lo; i < hi; ++i) dp[i] = pin[i]; });
+    }
   }
   return 0;
 }
@@ -424,6 +571,7 @@ fs_batch *fs_batch_create(const fs_batch_desc *desc) {
   if ((e = hipMemsetAsync(b->status, 0, B * 4, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
   if ((e = hipMemsetAsync(b->Yprev, 0, B * b->esz, b->stream)) != hipSuccess) return bad("hipMemsetAsync", e);
   if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return bad("hipStreamSynchronize", e);
+  if (B * N * b->esz >= kStageMin) (void)b->stage.init();        // large batch: the pinned chunks exist before the first transfer is timed
   (void)hipSetDevice(prev_dev >= 0 ? prev_dev : desc->device);
   return b;
 }
@@ -438,6 +586,7 @@ void fs_batch_destroy(fs_batch *b) {
                   b->reach_scheme, b->reach_kinds, b->kc_scratch};
   for (void *p : bufs) if (p) (void)hipFree(p);
   for (void *p : b->derived) if (p) (void)hipFree(p);
+  b->stage.release();
   if (b->ev0) (void)hipEventDestroy(b->ev0);
   if (b->ev1) (void)hipEventDestroy(b->ev1);
   if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -708,10 +857,13 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   if (!b || !h || !Q) return fail("fs_batch_set_state: null argument");
   FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches, N = b->d.n_nodes;
-  if (upload(b, &b->hk, h, B * N) || upload(b, &b->Qk, Q, B * N) || upload(b, &b->hg, h, B * N) || upload(b, &b->Qg, Q, B * N)) return -1;
+  // each array crosses the bus once; the Newton start vector and level 0 of the history are device-to-device copies
+  if (upload(b, &b->hk, h, B * N) || upload(b, &b->Qk, Q, B * N)) return -1;
+  HIP_TRY(hipMemcpyAsync(b->hg, b->hk, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
+  HIP_TRY(hipMemcpyAsync(b->Qg, b->Qk, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
   if (b->hist_h) {   // level 0 of the history = initial conditions (solver.py:61-63)
-    void *p = b->hist_h, *q = b->hist_Q;
-    if (upload(b, &p, h, B * N) || upload(b, &q, Q, B * N)) return -1;
+    HIP_TRY(hipMemcpyAsync(b->hist_h, b->hk, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->hist_Q, b->Qk, B * N * b->esz, hipMemcpyDeviceToDevice, b->stream));
   }
   std::vector<double> row(4 * B);
   for (size_t r = 0; r < B; ++r) {

@@ -242,8 +242,11 @@ class PreissmannBatch:
         return self._lib.fs_batch_level(self._h)
 
     # -- results --------------------------------------------------------------------------
-    def state(self):
-        h = np.empty((self.B, self.N)); Q = np.empty((self.B, self.N))
+    def state(self, out=None):
+        """depth[k], flow[k] of the current level, [B, N] each; out=(h, Q): filled in place (a caller that downloads every few
+        levels reuses its buffers instead of paying the page faults of fresh ones each time)"""
+        h, Q = out if out is not None else (np.empty((self.B, self.N)), np.empty((self.B, self.N)))
+        assert h.shape == Q.shape == (self.B, self.N) and h.dtype == Q.dtype == np.float64 and h.flags.c_contiguous and Q.flags.c_contiguous
         A.check(self._lib.fs_batch_get_state(self._h, _dptr(h), _dptr(Q)), "get_state")
         return h, Q
 
