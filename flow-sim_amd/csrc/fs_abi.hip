@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <limits>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -299,6 +300,9 @@ struct fs_batch {
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
   void *poly_x = nullptr, *poly_z = nullptr, *poly_lim = nullptr;
   int32_t *poly_n = nullptr;
+  void *poly_tz = nullptr, *poly_tc = nullptr;      // stage tables of the polylines (fs_poly.hpp)
+  int32_t *poly_ts = nullptr;
+  int poly_K = 0;
   size_t geo_reach_stride = 0, poly_reach_stride = 0;     // per-reach geometry (elements between the tables of two reaches), 0: shared
   int32_t *reach_nodes = nullptr;       // [B] per-reach node counts (heterogeneous batch) or nullptr
   void *reach_scheme = nullptr;         // [3][B] per-reach theta, dt, dx or nullptr
@@ -435,6 +439,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.geo_uniform = (const R *)b->geo_uniform; a.geo_table = (const R *)b->geo_table;
   a.n_override = (const R *)b->n_override;
   a.poly_x = (const R *)b->poly_x; a.poly_z = (const R *)b->poly_z; a.poly_lim = (const R *)b->poly_lim; a.poly_n = b->poly_n;
+  a.poly_tz = (const R *)b->poly_tz; a.poly_tc = (const R *)b->poly_tc; a.poly_ts = b->poly_ts; a.poly_K = b->poly_K;
   a.geo_reach_stride = (int64_t)b->geo_reach_stride; a.poly_reach_stride = (int64_t)b->poly_reach_stride;
   a.reach_nodes = b->reach_nodes; a.reach_scheme = (const R *)b->reach_scheme;
   a.reach_kinds = (b->kinds_per_reach[0] || b->kinds_per_reach[1]) ? b->reach_kinds : nullptr;
@@ -583,7 +588,7 @@ void fs_batch_destroy(fs_batch *b) {
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
-                  b->reach_scheme, b->reach_kinds, b->kc_scratch};
+                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->poly_tc, b->poly_ts};
   for (void *p : bufs) if (p) (void)hipFree(p);
   for (void *p : b->derived) if (p) (void)hipFree(p);
   b->stage.release();
@@ -637,8 +642,61 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 
 // polylines of one channel: validated and transposed into the vertex-major device layout ([P][N]; unused slots repeat the last
 // vertex so that no lane ever reads NaN).  Returns an error text or nullptr.
+// Stage table of one polyline (fs_poly.hpp): breakpoints = the distinct vertex elevations; for each interval between two of
+// them the polynomial coefficients of A, P, T and of the three roughness strips' (A, P) in u = stage - lower breakpoint, and
+// the number of wetted runs of >= 2 vertices.  Vertex-major like the polylines themselves: element j of node i at [j * N + i].
+static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, size_t N, size_t i, int P,
+                              double *tz, double *tc, int32_t *ts) {
+  std::vector<double> lev(zs, zs + c);
+  std::sort(lev.begin(), lev.end());
+  lev.erase(std::unique(lev.begin(), lev.end()), lev.end());
+  const int K = (int)lev.size();
+  const double inf = std::numeric_limits<double>::infinity();
+  for (int j = 0; j <= P; ++j) tz[(size_t)j * N + i] = j < K ? lev[j] : inf;
+  const double xa = xs[0], xb = xs[c - 1];
+  for (int k = 0; k < P; ++k) {
+    double co[fs::FS_PT_NCOEF] = {0};
+    int runs = 0;
+    if (k < K) {
+      const double z0k = lev[k];
+      auto wet = [&](int v) { return zs[v] <= z0k; };          // wet for every stage of the open interval above lev[k]
+      for (int e = 0; e + 1 < c; ++e) {
+        const double x0 = xs[e], x1 = xs[e + 1], za = zs[e], zb = zs[e + 1];
+        const double dx = x1 - x0, dz = zb - za, len = std::sqrt(dx * dx + dz * dz);
+        const bool w0 = wet(e), w1 = wet(e + 1);
+        double a0 = 0, a1 = 0, a2 = 0, p0 = 0, p1 = 0, t0 = 0, t1 = 0;
+        if (w0 && w1) {                                        // A = dx (s - zmid) = dx (z0k - zmid) + dx u
+          a0 = dx * (z0k - 0.5 * (za + zb)); a1 = dx; p0 = len; t0 = dx;
+        } else if (w0 != w1) {                                 // water's edge: (dx / 2|dz|) (s - zw)^2, (len / |dz|) (s - zw), (dx / |dz|) (s - zw)
+          const double zw = w0 ? za : zb, adz = std::fabs(dz), d = z0k - zw;
+          const double cA = 0.5 * dx / adz, cP = len / adz, cT = dx / adz;
+          a0 = cA * d * d; a1 = 2.0 * cA * d; a2 = cA; p0 = cP * d; p1 = cP; t0 = cT * d; t1 = cT;
+        } else {
+          continue;
+        }
+        co[fs::FS_PT_A0] += a0; co[fs::FS_PT_A1] += a1; co[fs::FS_PT_A2] += a2; co[fs::FS_PT_P0] += p0; co[fs::FS_PT_P1] += p1;
+        co[fs::FS_PT_T0] += t0; co[fs::FS_PT_T1] += t1;
+        const bool in[3] = {x0 >= xa && x1 <= liml, x0 >= liml && x1 <= limr, x0 >= limr && x1 <= xb};      // cross_section.py:459
+        for (int sidx = 0; sidx < 3; ++sidx)
+          if (in[sidx]) {
+            double *o = co + fs::FS_PT_STRIP + 5 * sidx;
+            o[0] += a0; o[1] += a1; o[2] += a2; o[3] += p0; o[4] += p1;
+          }
+      }
+      int run = 0;
+      for (int v = 0; v < c; ++v) {
+        if (wet(v)) ++run;
+        if (!wet(v) || v == c - 1) { runs += run >= 2; run = 0; }
+      }
+    }
+    for (int q = 0; q < fs::FS_PT_NCOEF; ++q) tc[((size_t)k * fs::FS_PT_NCOEF + q) * N + i] = co[q];
+    ts[(size_t)k * N + i] = runs;
+  }
+}
+
 static const char *pack_polylines(const double *table, const int32_t *n_pts, int32_t max_pts, const double *x, const double *z,
-                                  const double *limits, size_t N, double *xt, double *zt, double *lim) {
+                                  const double *limits, size_t N, double *xt, double *zt, double *lim, double *tz, double *tc,
+                                  int32_t *ts) {
   const size_t P = max_pts;
   for (size_t i = 0; i < N; ++i) {
     const int c = n_pts[i];
@@ -658,6 +716,7 @@ static const char *pack_polylines(const double *table, const int32_t *n_pts, int
       xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
     }
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
+    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], N, i, max_pts, tz, tc, ts);
   }
   return nullptr;
 }
@@ -672,17 +731,28 @@ static int set_irregular(fs_batch *b, const double *table, const int32_t *n_pts,
   FS_ON_DEVICE(b);
   const size_t N = b->d.n_nodes, P = max_pts, per = (size_t)fs::FS_GEOX_NROWS * N;
   std::vector<double> xt(n_sets * P * N, 0.0), zt(n_sets * P * N, 0.0), lim(n_sets * 2 * N, 0.0), tabs(n_sets * per);
+  std::vector<double> tz(n_sets * (P + 1) * N, std::numeric_limits<double>::infinity()), tc(n_sets * P * fs::FS_PT_NCOEF * N, 0.0);
+  std::vector<int32_t> ts(n_sets * P * N, 0);
   for (size_t r = 0; r < n_sets; ++r) {
     const double *tab_r = table + r * FS_GEO_NPARAM * N;
     if (const char *err = pack_polylines(tab_r, n_pts + r * N, max_pts, x + r * N * P, z + r * N * P, limits + r * 2 * N, N,
-                                         xt.data() + r * P * N, zt.data() + r * P * N, lim.data() + r * 2 * N))
+                                         xt.data() + r * P * N, zt.data() + r * P * N, lim.data() + r * 2 * N,
+                                         tz.data() + r * (P + 1) * N, tc.data() + r * P * fs::FS_PT_NCOEF * N, ts.data() + r * P * N))
       return fail(err);
     const std::vector<double> ext = extend_table(tab_r, N);
     std::memcpy(tabs.data() + r * per, ext.data(), per * sizeof(double));
   }
-  void **old[] = {&b->geo_table, &b->poly_x, &b->poly_z, &b->poly_lim};
+  void **old[] = {&b->geo_table, &b->poly_x, &b->poly_z, &b->poly_lim, &b->poly_tz, &b->poly_tc};
   for (void **q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
   if (b->poly_n) { (void)hipFree(b->poly_n); b->poly_n = nullptr; }
+  if (b->poly_ts) { (void)hipFree(b->poly_ts); b->poly_ts = nullptr; }
+  b->poly_K = 0;
+  if (!std::getenv("FS_POLY_WALK")) {          // (FS_POLY_WALK=1: no stage tables, every evaluation walks the edges - the round-2 path, kept for comparison)
+    if (upload(b, &b->poly_tz, tz.data(), tz.size()) || upload(b, &b->poly_tc, tc.data(), tc.size())) return -1;
+    HIP_TRY(hipMalloc((void **)&b->poly_ts, ts.size() * 4));
+    HIP_TRY(hipMemcpy(b->poly_ts, ts.data(), ts.size() * 4, hipMemcpyHostToDevice));
+    b->poly_K = (int)P;
+  }
   if (upload(b, &b->geo_table, tabs.data(), tabs.size()) || upload(b, &b->poly_x, xt.data(), xt.size()) ||
       upload(b, &b->poly_z, zt.data(), zt.size()) || upload(b, &b->poly_lim, lim.data(), lim.size())) return -1;
   HIP_TRY(hipMalloc((void **)&b->poly_n, n_sets * N * 4));

@@ -165,6 +165,9 @@ template <typename R> struct KernelArgs {
   const R *poly_x, *poly_z;      // IRREGULAR: [P][N] polyline stations / elevations (vertex-major)
   const R *poly_lim;             // IRREGULAR: [2][N] roughness strip limits
   const int32_t *poly_n;         // IRREGULAR: [N] vertex counts (0 = trapezoid-family node of the table)
+  const R *poly_tz, *poly_tc;    // IRREGULAR: stage tables (fs_poly.hpp): [P + 1][N] breakpoints, [P][FS_PT_NCOEF][N] coefficients
+  const int32_t *poly_ts;        // IRREGULAR: [P][N] wetted runs per interval
+  int32_t poly_K;                // IRREGULAR: P, rows of the stage tables (0: no tables, walk the edges)
   BCDesc<R> us, ds;
   R *Yprev;                // [B] storage stage of the current level
   R *stage_hist;           // [levels][B] storage stage per level (boundary.py:126-131)
@@ -313,13 +316,19 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_general_call(const SecParams<R> 
 template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   static constexpr bool kConstT = false;
   Geometry<R, FS_SEC_TABLE> tb;
-  const R *px, *pz, *plim;
-  const int32_t *pn;
+  const R *px, *pz, *plim, *ptz, *ptc;
+  const int32_t *pn, *pts;
+  int pK;
   __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int n_nodes) {
     tb.init(a, reach, n_nodes);
     const bool own = a.poly_reach_stride != 0;
     px = a.poly_x + (size_t)reach * a.poly_reach_stride; pz = a.poly_z + (size_t)reach * a.poly_reach_stride;
     plim = a.poly_lim + (own ? (size_t)reach * 2 * a.N : 0); pn = a.poly_n + (own ? (size_t)reach * a.N : 0);
+    pK = a.poly_K;                                     // stage tables: [P + 1][N], [P][NCOEF][N], [P][N] per reach (or shared)
+    const size_t pr = own ? (size_t)reach : 0;
+    ptz = pK ? a.poly_tz + pr * (size_t)(pK + 1) * a.N : nullptr;
+    ptc = pK ? a.poly_tc + pr * (size_t)pK * FS_PT_NCOEF * a.N : nullptr;
+    pts = pK ? a.poly_ts + pr * (size_t)pK * a.N : nullptr;
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }
   __device__ __forceinline__ R rT_const() const { return R(0); }
@@ -334,12 +343,16 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     p.nl = g(FS_GEO_N_LEFT); p.nm = tb.has_over ? tb.n_over : g(FS_GEO_N_MAIN); p.nr = g(FS_GEO_N_RIGHT);
     p.liml = plim[node]; p.limr = plim[N + node];
     p.curv = g(FS_GEO_CURVATURE); p.zmin = g(FS_GEO_Z_BED);
+    p.tz = ptz ? ptz + node : nullptr; p.tc = ptc ? ptc + node : nullptr; p.ts = pts ? pts + node : nullptr; p.K = pK;
     return p;
   }
-  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
-    if (pn[node] > 0) return node_terms_poly(poly(node), h, Q);
+  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q, int *kcache = nullptr) const {
+    if (pn[node] > 0) return node_terms_poly(poly(node), h, Q, kcache);
     return node_terms_general_call(section(node), h, Q);
   }
+  // the same out of line: the kernels with many rows per lane evaluate 2 (M + 1) nodes per iteration - inlined, the polyline
+  // code made them ~30 000 instructions long (and the 4-wave one of them miscompiled); two rows per lane keep it inline (+37 %)
+  __device__ __noinline__ NodeTerms<R> terms_call(int node, R h, R Q) const { return terms(node, h, Q); }
   template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc_, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
@@ -348,8 +361,9 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
       return bc_normal_depth_poly(poly(node), ((LdsParams<R>)bc.params)[0], ((LdsParams<R>)bc.params)[1], h, Q);   // (LDS copy, as bc_eval)
     if (BCK != 0 && pn[node] > 0 && bc.kind == FS_BC_STORAGE_CURVE) {
       const PolyNode<R> nd = poly(node);
-      const PolyEval<R> er = poly_eval(nd, poly_whole(nd), nd.zmin + h);
-      const PolyEval<R> ed = poly_eval(nd, poly_whole(nd), h + bc_param(bc, FS_SC_BED_LEVEL, reach, B));
+      int ns_;
+      const PolyEval<R> er = poly_eval_whole(nd, nd.zmin + h, &ns_);
+      const PolyEval<R> ed = poly_eval_whole(nd, h + bc_param(bc, FS_SC_BED_LEVEL, reach, B), &ns_);
       EntryProps<R> pr{er.A, er.Rh, er.neq, er.dRdA, er.dAdh}, pd{ed.A, ed.Rh, ed.neq, ed.dRdA, ed.dAdh};
       return bc_storage_curve(bc, reach, B, level, pr, pd, h, Q, Qold, dt, Yprev, Ynew, flag);
     }
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   }
   auto terms_at = [&](int j, R hh, R QQ) {
     if constexpr (kRegGeo) return node_terms_general(secs[j], hh, QQ);
+    else if constexpr (SEC == FS_SEC_IRREGULAR && M > 2) return geo.terms_call(min(s0 + j, N - 1), hh, QQ);
     else return geo.terms(min(s0 + j, N - 1), hh, QQ);
   };
 
@@ -1186,6 +1201,7 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
         const size_t po = (size_t)reach * a.poly_reach_stride, no = a.poly_reach_stride ? (size_t)reach * a.N : 0;
         if (a.poly_n[no + node] > 0) {
           pnode[e].x = a.poly_x + po + node; pnode[e].z = a.poly_z + po + node; pnode[e].stride = a.N; pnode[e].n = a.poly_n[no + node];
+          pnode[e].tz = nullptr; pnode[e].tc = nullptr; pnode[e].ts = nullptr; pnode[e].K = 0;
         }
       }
     } else {

@@ -90,6 +90,10 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
   if (warn) status = FS_OK;
   if (t == 0) { sm.xflag = 0; sm.xwarn = 0; }
 
+  auto node_terms = [&](int node, R hh, R QQ) {
+    if constexpr (SEC == FS_SEC_IRREGULAR) return geo.terms_call(node, hh, QQ);        // (out of line: see Geometry<R, FS_SEC_IRREGULAR>)
+    else return geo.terms(node, hh, QQ);
+  };
   // nodes g0 .. g0 + M of a pass's lane (clamped copies beyond the last node)
   auto load_nodes = [&](const R *hs, const R *Qs, int g0, R(&h)[M + 1], R(&Q)[M + 1]) {
 #pragma unroll
@@ -100,10 +104,10 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
   };
   auto kc_at = [&](int i, int p, int c) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
   auto write_level_constants = [&](int p, int g0, const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
-    NodeTerms<R> L = geo.terms(min(g0, N - 1), hh[0], QQ[0]);
+    NodeTerms<R> L = node_terms(min(g0, N - 1), hh[0], QQ[0]);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
-      const NodeTerms<R> Rn = geo.terms(min(g0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
+      const NodeTerms<R> Rn = node_terms(min(g0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
       const R sumA = L.A + Rn.A;
       kc_at(0, p, c) = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
       kc_at(1, p, c) = fma_(cqk, fma_(QQ[c + 1], Rn.v, -(QQ[c] * L.v)), -((QQ[c + 1] + QQ[c]) * r2dt));
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
           seg.u1 = R(0); seg.u3 = R(-1); seg.ru = R(0);
           R rcLast;
           {
-            NodeTerms<R> L = geo.terms(min(g0, N - 1), h[0], Q[0]);
+            NodeTerms<R> L = node_terms(min(g0, N - 1), h[0], Q[0]);
             R i2tL = dt * L.rT;
             iTn[0] = i2tL;
             if (p == 0 && t == 0 && phase == 0) {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
 #pragma unroll
             for (int c = 0; c < M; ++c) {
               const R k0 = kc_at(0, p, c), k1 = kc_at(1, p, c), k2 = kc_at(2, p, c), k3 = kc_at(3, p, c);
-              const NodeTerms<R> Rn = geo.terms(min(g0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
+              const NodeTerms<R> Rn = node_terms(min(g0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
               const R i2tR = dt * Rn.rT;
               iTn[c + 1] = i2tR;
               Row<R> row;

@@ -39,7 +39,21 @@ template <typename R> struct PolyNode {
   const R *x, *z;
   int stride, n;
   R nl, nm, nr, liml, limr, curv, zmin;
+  // stage table of the node (fs_abi.hip: build_stage_table), same vertex-major layout; tz == nullptr: no table, walk the edges
+  const R *tz;             // [K + 1] breakpoints: the distinct vertex elevations, ascending, padded with +inf
+  const R *tc;             // [K][FS_PT_NCOEF] coefficients of interval k = (tz[k], tz[k + 1]] in u = stage - tz[k]
+  const int32_t *ts;       // [K] wetted runs of >= 2 vertices in interval k (get_subchannels, cross_section.py:330-370)
+  int K;
 };
+
+// Stage table.  Between two consecutive vertex elevations the set of wet vertices is fixed, and what properties() /
+// get_equivalent_n() sum edge by edge (cross_section.py:248-328, :449-500) are low-order polynomials of the stage:
+//   an edge wet at both ends adds   dx (s - zmid)            to A,  its length to P,  dx to T;
+//   a water's-edge edge adds        (dx / 2|dz|) (s - zw)^2  to A,  (len / |dz|) (s - zw) to P,  (dx / |dz|) (s - zw) to T
+// (zw: elevation of its wet end).  Expanded in u = s - tz[k] >= 0 every coefficient is a sum of non-negative terms - no
+// cancellation, so the 1e-6 finite differences of dR_dA / dA_dh (:523-538) survive.  Per interval: whole section A (3), P (2),
+// T (2), then A (3) and P (2) of the left, main and right roughness strips (an edge belongs to a strip by its two stations, :459).
+enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1, FS_PT_STRIP = 7, FS_PT_NCOEF = 22 };
 
 // vertices [lo, hi] of a node, optionally extended by a water's-edge point at elevation zc on
 // either side (the x_seg / z_seg of cross_section.py:352-365)
@@ -82,9 +96,12 @@ template <typename R> __device__ __forceinline__ R strip_K(R A, R P, R n) {   //
   return (A <= R(0) || P <= R(0)) ? R(0) : conv_(A, n, A * frcp(P));
 }
 
-// properties / get_equivalent_n / conveyance / dR_dA / dK_dA / dA_dh of one (sub-)section at stage hw
+// what one pass over the edges of a (sub-)section accumulates: (A, P) at the stages hw, hw - dh, hw + dh, the top width at hw
+// and (A, P) of the three roughness strips at hw
+template <typename R> struct PolySums { R A0, P0, T0, A1, P1, A2, P2, Al, Pl, Am, Pm, Ar, Pr; };
+
 template <typename R>
-__device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyView<R> v, R hw) {
+__device__ FS_POLY_ATTR PolySums<R> poly_sums_walk(const PolyNode<R> nd, const PolyView<R> v, R hw) {
   const R dh = R(1e-6);
   const int j0 = v.lo - (v.vl ? 1 : 0), j1 = v.hi + (v.vr ? 1 : 0);
   auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : nd.x[(size_t)j * nd.stride]); };
@@ -118,14 +135,24 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
     if (x0 >= nd.limr && x1 <= xb) { Ar += eA; Pr += eP; }
     x0 = x1; z0 = z1;
   }
+  PolySums<R> q;
+  q.A0 = A0; q.P0 = P0; q.T0 = T0; q.A1 = A1; q.P1 = P1; q.A2 = A2; q.P2 = P2;
+  q.Al = Al; q.Pl = Pl; q.Am = Am; q.Pm = Pm; q.Ar = Ar; q.Pr = Pr;
+  return q;
+}
+
+// properties / get_equivalent_n / conveyance / dR_dA / dK_dA / dA_dh from the sums of a (sub-)section
+template <typename R>
+__device__ __forceinline__ PolyEval<R> poly_finish(const PolyNode<R> &nd, const PolySums<R> &q) {
+  const R A0 = q.A0, P0 = q.P0, A1 = q.A1, P1 = q.P1, A2 = q.A2, P2 = q.P2;
   PolyEval<R> e;
-  e.A = A0; e.P = P0; e.T = T0;
+  e.A = A0; e.P = P0; e.T = q.T0;
   e.Rh = P0 > R(0) ? A0 * frcp(P0) : R(0);
   e.y13 = e.Rh > R(0) ? rcbrt_pos(e.Rh) : R(0);
   const R R23 = e.Rh * e.y13;
   e.neq = nd.nm;                                                        // :486-487 fallback
   if (A0 > R(0) && P0 > R(0)) {
-    const R Kt = p23_(p32_(strip_K(Al, Pl, nd.nl)) + p32_(strip_K(Am, Pm, nd.nm)) + p32_(strip_K(Ar, Pr, nd.nr)));
+    const R Kt = p23_(p32_(strip_K(q.Al, q.Pl, nd.nl)) + p32_(strip_K(q.Am, q.Pm, nd.nm)) + p32_(strip_K(q.Ar, q.Pr, nd.nr)));
     if (Kt > R(0)) e.neq = A0 * R23 * frcp(Kt);                         // :492-498
   }
   const R rneq = frcp(e.neq);
@@ -138,22 +165,95 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyVi
   return e;
 }
 
+template <typename R>
+__device__ FS_POLY_ATTR PolyEval<R> poly_eval(const PolyNode<R> nd, const PolyView<R> v, R hw) {
+  return poly_finish(nd, poly_sums_walk(nd, v, hw));
+}
+
 template <typename R> __device__ __forceinline__ PolyView<R> poly_whole(const PolyNode<R> &nd) {
   PolyView<R> v;
   v.lo = 0; v.hi = nd.n - 1; v.vl = false; v.vr = false; v.xl = R(0); v.xr = R(0); v.zc = R(0);
   return v;
 }
 
+// The whole section at stage hw from the node's stage table: one scan over the breakpoints places the three stages, then
+// ~25 coefficient loads and as many fmas stand in for the walk over all edges.  *nsub returns the number of wetted runs of
+// >= 2 vertices (1 when there is no table: the caller then counts them itself).  A stage that coincides with a vertex
+// elevation to the last bit goes back to the edge walk (there the reference drops the two edges at that vertex, :262).
+// The edge walk over the whole section, out of line: with stage tables it only runs when a stage hits a vertex elevation to the
+// last bit (or when the tables are switched off, FS_POLY_WALK=1).  Inlined at every node evaluation next to the table path it
+// made the 4-wave polyline kernel 30 000 instructions long, and that kernel then died at launch (long-branch expansion with no
+// scalar register to spare); the sub-section walks of a split section stay inline, as before.
+template <typename R>
+__device__ __noinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R hw) {
+  return poly_finish(nd, poly_sums_walk(nd, poly_whole(nd), hw));
+}
+
+template <typename R>
+__device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, int *nsub, int *kcache = nullptr) {
+  *nsub = -1;                                   // unknown: the caller counts the runs
+  if (nd.tz == nullptr) return poly_eval_whole_walk(nd, hw);
+  const R dh = R(1e-6);
+  const R s1 = hw - dh, s2 = hw + dh;
+  int c0 = 0, c1 = 0, c2 = 0;
+  // a node's stage moves little from one Newton iteration to the next: a caller may keep the interval of its last evaluation;
+  // two loads then confirm that all three stages still lie strictly inside it and stand in for the scan.  (Measured on the
+  // polyline ensemble with the three intervals of a lane kept in registers: 1.35e7 -> 1.31e7 - the kernel sits on its 256-register
+  // cap and the three integers cost more in spills than the 13 loads they save; no caller passes a cache today.)
+  bool hit = false;
+  if (kcache != nullptr && *kcache >= 0) {
+    const int k = *kcache;
+    hit = nd.tz[(size_t)k * nd.stride] < s1 && s2 < nd.tz[(size_t)(k + 1) * nd.stride];
+    c0 = c1 = c2 = k + 1;
+  }
+  if (!hit) {
+    c0 = c1 = c2 = 0;
+    bool exact = false;
+    for (int j = 0; j < nd.K; ++j) {
+      const R zb = nd.tz[(size_t)j * nd.stride];
+      c0 += zb < hw; c1 += zb < s1; c2 += zb < s2;
+      exact = exact || zb == hw || zb == s1 || zb == s2;
+    }
+    if (exact) return poly_eval_whole_walk(nd, hw);
+    if (kcache != nullptr) *kcache = c0 - 1;
+  }
+  PolySums<R> q;
+  q.A0 = q.P0 = q.T0 = q.A1 = q.P1 = q.A2 = q.P2 = q.Al = q.Pl = q.Am = q.Pm = q.Ar = q.Pr = R(0);
+  *nsub = 0;
+  if (c2 > 0) {
+    auto co = [&](int k, int i) { return nd.tc[((size_t)k * FS_PT_NCOEF + i) * nd.stride]; };
+    auto zk = [&](int k) { return nd.tz[(size_t)k * nd.stride]; };
+    auto area = [&](int k, R u) { return fma_(fma_(co(k, FS_PT_A2), u, co(k, FS_PT_A1)), u, co(k, FS_PT_A0)); };
+    auto peri = [&](int k, R u) { return fma_(co(k, FS_PT_P1), u, co(k, FS_PT_P0)); };
+    if (c0 > 0) {
+      const int k = c0 - 1;
+      const R u = hw - zk(k);
+      q.A0 = area(k, u); q.P0 = peri(k, u); q.T0 = fma_(co(k, FS_PT_T1), u, co(k, FS_PT_T0));
+      auto strip = [&](int sidx, R &A, R &P) {
+        const int o = FS_PT_STRIP + 5 * sidx;
+        A = fma_(fma_(co(k, o + 2), u, co(k, o + 1)), u, co(k, o));
+        P = fma_(co(k, o + 4), u, co(k, o + 3));
+      };
+      strip(0, q.Al, q.Pl); strip(1, q.Am, q.Pm); strip(2, q.Ar, q.Pr);
+      *nsub = nd.ts[(size_t)k * nd.stride];
+    }
+    if (c1 > 0) { const int k = c1 - 1; const R u = s1 - zk(k); q.A1 = area(k, u); q.P1 = peri(k, u); }
+    { const int k = c2 - 1; const R u = s2 - zk(k); q.A2 = area(k, u); q.P2 = peri(k, u); }
+  }
+  return poly_finish(nd, q);
+}
+
 // Se, dSe/dA, dSe/dQ, A, dA/dh of a polyline node: friction_slope / dSf_dA / dSf_dQ of
 // cross_section.py:372-447 (sub-channel sum when >= 2 wetted runs) plus the base-class curvature terms.
 template <typename R>
-__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
+__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q, int *kcache = nullptr) {
   const R hw = h + nd.zmin;
-  const PolyEval<R> e = poly_eval(nd, poly_whole(nd), hw);
-  R K = e.K, dK = e.dKdA;
-  // wetted runs of >= 2 vertices (get_subchannels, :330-370)
   int nsub = 0;
-  {
+  const PolyEval<R> e = poly_eval_whole(nd, hw, &nsub, kcache);
+  R K = e.K, dK = e.dKdA;
+  // wetted runs of >= 2 vertices (get_subchannels, :330-370): from the stage table, else counted here
+  if (nsub < 0) {
+    nsub = 0;
     int run = 0;
     for (int j = 0; j < nd.n; ++j) {
       const bool wet = nd.z[(size_t)j * nd.stride] < hw;
@@ -211,11 +311,12 @@ template <typename R>
 __device__ FS_POLY_ATTR BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0, R bed, R h, R Q) {
   const R sg = S0 < R(0) ? R(-1) : R(1);
   const R rt = sqrt_(fabs_(S0));
-  const PolyEval<R> gr = poly_eval(nd, poly_whole(nd), nd.zmin + h);
+  int ns_;
+  const PolyEval<R> gr = poly_eval_whole(nd, nd.zmin + h, &ns_);
   // boundary.py:165-181 takes the residual at the section's own datum and the derivative at the boundary's bed level; they
   // are usually the same stage, and a section walk here costs the reach's only wave as much as a node of the fold
   PolyEval<R> gd = gr;
-  if (h + bed != nd.zmin + h) gd = poly_eval(nd, poly_whole(nd), h + bed);
+  if (h + bed != nd.zmin + h) gd = poly_eval_whole(nd, h + bed, &ns_);
   BCRow<R> r;
   r.res = Q - sg * gr.K * rt;
   r.dh = R(0) - sg * gd.dKdA * rt * gd.dAdh;

@@ -3,7 +3,7 @@
 #   kernel trace + stats, then the HBM traffic counters in separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
 #   do not fit one pass; counters are never combined with system traces), the issue counters and the flop counters.
 # Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round3/.
-set -e
+set -e; mkdir -p $(pwd)/gpurun_out/prof
 TAG=$1; shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof/$TAG
