@@ -300,8 +300,7 @@ struct fs_batch {
   void *geo_uniform = nullptr, *geo_table = nullptr, *n_override = nullptr;
   void *poly_x = nullptr, *poly_z = nullptr, *poly_lim = nullptr;
   int32_t *poly_n = nullptr;
-  void *poly_tz = nullptr, *poly_tc = nullptr;      // stage tables of the polylines (fs_poly.hpp)
-  int32_t *poly_ts = nullptr;
+  void *poly_tz = nullptr;              // stage tables of the polylines (fs_poly.hpp)
   int poly_K = 0;
   size_t geo_reach_stride = 0, poly_reach_stride = 0;     // per-reach geometry (elements between the tables of two reaches), 0: shared
   int32_t *reach_nodes = nullptr;       // [B] per-reach node counts (heterogeneous batch) or nullptr
@@ -439,7 +438,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.geo_uniform = (const R *)b->geo_uniform; a.geo_table = (const R *)b->geo_table;
   a.n_override = (const R *)b->n_override;
   a.poly_x = (const R *)b->poly_x; a.poly_z = (const R *)b->poly_z; a.poly_lim = (const R *)b->poly_lim; a.poly_n = b->poly_n;
-  a.poly_tz = (const R *)b->poly_tz; a.poly_tc = (const R *)b->poly_tc; a.poly_ts = b->poly_ts; a.poly_K = b->poly_K;
+  a.poly_tz = (const R *)b->poly_tz; a.poly_K = b->poly_K;
   a.geo_reach_stride = (int64_t)b->geo_reach_stride; a.poly_reach_stride = (int64_t)b->poly_reach_stride;
   a.reach_nodes = b->reach_nodes; a.reach_scheme = (const R *)b->reach_scheme;
   a.reach_kinds = (b->kinds_per_reach[0] || b->kinds_per_reach[1]) ? b->reach_kinds : nullptr;
@@ -588,7 +587,7 @@ void fs_batch_destroy(fs_batch *b) {
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
-                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->poly_tc, b->poly_ts};
+                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz};
   for (void *p : bufs) if (p) (void)hipFree(p);
   for (void *p : b->derived) if (p) (void)hipFree(p);
   b->stage.release();
@@ -644,18 +643,18 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 // vertex so that no lane ever reads NaN).  Returns an error text or nullptr.
 // Stage table of one polyline (fs_poly.hpp): breakpoints = the distinct vertex elevations; for each interval between two of
 // them the polynomial coefficients of A, P, T and of the three roughness strips' (A, P) in u = stage - lower breakpoint, and
-// the number of wetted runs of >= 2 vertices.  Vertex-major like the polylines themselves: element j of node i at [j * N + i].
-static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, size_t N, size_t i, int P,
-                              double *tz, double *tc, int32_t *ts) {
+// the number of wetted runs of >= 2 vertices.  One contiguous block per node: [KP] breakpoints, then [P][FS_PT_BLOCK].
+static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, int P, double *blk) {
   std::vector<double> lev(zs, zs + c);
   std::sort(lev.begin(), lev.end());
   lev.erase(std::unique(lev.begin(), lev.end()), lev.end());
-  const int K = (int)lev.size();
+  const int K = (int)lev.size(), KP = fs::poly_table_bp(P);
   const double inf = std::numeric_limits<double>::infinity();
-  for (int j = 0; j <= P; ++j) tz[(size_t)j * N + i] = j < K ? lev[j] : inf;
+  for (int j = 0; j < KP; ++j) blk[j] = j < K ? lev[j] : inf;
   const double xa = xs[0], xb = xs[c - 1];
   for (int k = 0; k < P; ++k) {
-    double co[fs::FS_PT_NCOEF] = {0};
+    double *co = blk + KP + (size_t)k * fs::FS_PT_BLOCK;
+    for (int q = 0; q < fs::FS_PT_BLOCK; ++q) co[q] = 0.0;
     int runs = 0;
     if (k < K) {
       const double z0k = lev[k];
@@ -689,14 +688,12 @@ static void build_stage_table(const double *xs, const double *zs, int c, double 
         if (!wet(v) || v == c - 1) { runs += run >= 2; run = 0; }
       }
     }
-    for (int q = 0; q < fs::FS_PT_NCOEF; ++q) tc[((size_t)k * fs::FS_PT_NCOEF + q) * N + i] = co[q];
-    ts[(size_t)k * N + i] = runs;
+    co[fs::FS_PT_NSUB] = (double)runs;
   }
 }
 
 static const char *pack_polylines(const double *table, const int32_t *n_pts, int32_t max_pts, const double *x, const double *z,
-                                  const double *limits, size_t N, double *xt, double *zt, double *lim, double *tz, double *tc,
-                                  int32_t *ts) {
+                                  const double *limits, size_t N, double *xt, double *zt, double *lim, double *tz) {
   const size_t P = max_pts;
   for (size_t i = 0; i < N; ++i) {
     const int c = n_pts[i];
@@ -716,7 +713,7 @@ static const char *pack_polylines(const double *table, const int32_t *n_pts, int
       xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
     }
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
-    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], N, i, max_pts, tz, tc, ts);
+    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], max_pts, tz + i * (size_t)fs::poly_table_stride(max_pts));
   }
   return nullptr;
 }
@@ -731,26 +728,23 @@ static int set_irregular(fs_batch *b, const double *table, const int32_t *n_pts,
   FS_ON_DEVICE(b);
   const size_t N = b->d.n_nodes, P = max_pts, per = (size_t)fs::FS_GEOX_NROWS * N;
   std::vector<double> xt(n_sets * P * N, 0.0), zt(n_sets * P * N, 0.0), lim(n_sets * 2 * N, 0.0), tabs(n_sets * per);
-  std::vector<double> tz(n_sets * (P + 1) * N, std::numeric_limits<double>::infinity()), tc(n_sets * P * fs::FS_PT_NCOEF * N, 0.0);
-  std::vector<int32_t> ts(n_sets * P * N, 0);
+  const size_t tstride = (size_t)fs::poly_table_stride(max_pts);
+  std::vector<double> tz(n_sets * N * tstride, std::numeric_limits<double>::infinity());
   for (size_t r = 0; r < n_sets; ++r) {
     const double *tab_r = table + r * FS_GEO_NPARAM * N;
     if (const char *err = pack_polylines(tab_r, n_pts + r * N, max_pts, x + r * N * P, z + r * N * P, limits + r * 2 * N, N,
                                          xt.data() + r * P * N, zt.data() + r * P * N, lim.data() + r * 2 * N,
-                                         tz.data() + r * (P + 1) * N, tc.data() + r * P * fs::FS_PT_NCOEF * N, ts.data() + r * P * N))
+                                         tz.data() + r * N * tstride))
       return fail(err);
     const std::vector<double> ext = extend_table(tab_r, N);
     std::memcpy(tabs.data() + r * per, ext.data(), per * sizeof(double));
   }
-  void **old[] = {&b->geo_table, &b->poly_x, &b->poly_z, &b->poly_lim, &b->poly_tz, &b->poly_tc};
+  void **old[] = {&b->geo_table, &b->poly_x, &b->poly_z, &b->poly_lim, &b->poly_tz};
   for (void **q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
   if (b->poly_n) { (void)hipFree(b->poly_n); b->poly_n = nullptr; }
-  if (b->poly_ts) { (void)hipFree(b->poly_ts); b->poly_ts = nullptr; }
   b->poly_K = 0;
   if (!std::getenv("FS_POLY_WALK")) {          // (FS_POLY_WALK=1: no stage tables, every evaluation walks the edges - the round-2 path, kept for comparison)
-    if (upload(b, &b->poly_tz, tz.data(), tz.size()) || upload(b, &b->poly_tc, tc.data(), tc.size())) return -1;
-    HIP_TRY(hipMalloc((void **)&b->poly_ts, ts.size() * 4));
-    HIP_TRY(hipMemcpy(b->poly_ts, ts.data(), ts.size() * 4, hipMemcpyHostToDevice));
+    if (upload(b, &b->poly_tz, tz.data(), tz.size())) return -1;
     b->poly_K = (int)P;
   }
   if (upload(b, &b->geo_table, tabs.data(), tabs.size()) || upload(b, &b->poly_x, xt.data(), xt.size()) ||

@@ -176,9 +176,8 @@ template <typename R> struct KernelArgs {
   const int32_t *reach_nodes;    // [B] or nullptr: nodes of each reach (<= N; N stays the row stride of every [B][N] array)
   const R *reach_scheme;         // [3][B] or nullptr: theta, dt, dx of each reach
   const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE)
-  const R *poly_tz, *poly_tc;    // IRREGULAR: stage tables (fs_poly.hpp): [P + 1][N] breakpoints, [P][FS_PT_NCOEF][N] coefficients
-  const int32_t *poly_ts;        // IRREGULAR: [P][N] wetted runs per interval
-  int32_t poly_K;                // IRREGULAR: P, rows of the stage tables (0: no tables, walk the edges)
+  const R *poly_tz;              // IRREGULAR: stage tables (fs_poly.hpp): [N][poly_table_stride(P)], one block per node
+  int32_t poly_K;                // IRREGULAR: P, intervals per node in the stage tables (0: no tables, walk the edges)
   R *kc_scratch;           // long reaches (fs_long.hpp): [B][4][passes * 64 W M] level constants, owned by the batch
   int32_t passes;          // long reaches: passes of 64 W M rows a workgroup makes over its reach
 };
@@ -318,19 +317,16 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_general_call(const SecParams<R> 
 template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   static constexpr bool kConstT = false;
   Geometry<R, FS_SEC_TABLE> tb;
-  const R *px, *pz, *plim, *ptz, *ptc;
-  const int32_t *pn, *pts;
+  const R *px, *pz, *plim, *ptz;
+  const int32_t *pn;
   int pK;
   __device__ __forceinline__ void init(const KernelArgs<R> &a, int reach, int n_nodes) {
     tb.init(a, reach, n_nodes);
     const bool own = a.poly_reach_stride != 0;
     px = a.poly_x + (size_t)reach * a.poly_reach_stride; pz = a.poly_z + (size_t)reach * a.poly_reach_stride;
     plim = a.poly_lim + (own ? (size_t)reach * 2 * a.N : 0); pn = a.poly_n + (own ? (size_t)reach * a.N : 0);
-    pK = a.poly_K;                                     // stage tables: [P + 1][N], [P][NCOEF][N], [P][N] per reach (or shared)
-    const size_t pr = own ? (size_t)reach : 0;
-    ptz = pK ? a.poly_tz + pr * (size_t)(pK + 1) * a.N : nullptr;
-    ptc = pK ? a.poly_tc + pr * (size_t)pK * FS_PT_NCOEF * a.N : nullptr;
-    pts = pK ? a.poly_ts + pr * (size_t)pK * a.N : nullptr;
+    pK = a.poly_K;                                     // stage tables: [N][poly_table_stride(P)] per reach (or shared)
+    ptz = pK ? a.poly_tz + (own ? (size_t)reach * a.N * poly_table_stride(pK) : 0) : nullptr;
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }
   __device__ __forceinline__ R rT_const() const { return R(0); }
@@ -340,16 +336,18 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   __device__ __forceinline__ PolyNode<R> poly(int node) const {
     PolyNode<R> p;
     const int N = tb.N;
-    auto g = [&](int row) { return tb.tab[(size_t)row * N + node]; };
-    p.x = px + node; p.z = pz + node; p.stride = N; p.n = pn[node];
+    typedef const __attribute__((address_space(1))) R *GlobalR;              // (device memory: global loads, not flat ones)
+    typedef const __attribute__((address_space(1))) int32_t *GlobalI;
+    auto g = [&](int row) { return ((GlobalR)tb.tab)[(size_t)row * N + node]; };
+    p.x = px + node; p.z = pz + node; p.stride = N; p.n = ((GlobalI)pn)[node];
     p.nl = g(FS_GEO_N_LEFT); p.nm = tb.has_over ? tb.n_over : g(FS_GEO_N_MAIN); p.nr = g(FS_GEO_N_RIGHT);
-    p.liml = plim[node]; p.limr = plim[N + node];
+    p.liml = ((GlobalR)plim)[node]; p.limr = ((GlobalR)plim)[N + node];
     p.curv = g(FS_GEO_CURVATURE); p.zmin = g(FS_GEO_Z_BED);
-    p.tz = ptz ? ptz + node : nullptr; p.tc = ptc ? ptc + node : nullptr; p.ts = pts ? pts + node : nullptr; p.K = pK;
+    p.tz = ptz ? ptz + (size_t)node * poly_table_stride(pK) : nullptr; p.K = pK; p.KP = poly_table_bp(pK);
     return p;
   }
-  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q, int *kcache = nullptr) const {
-    if (pn[node] > 0) return node_terms_poly(poly(node), h, Q, kcache);
+  __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
+    if (((const __attribute__((address_space(1))) int32_t *)pn)[node] > 0) return node_terms_poly(poly(node), h, Q);
     return node_terms_general_call(section(node), h, Q);
   }
   // the same out of line: the kernels with many rows per lane evaluate 2 (M + 1) nodes per iteration - inlined, the polyline
@@ -486,15 +484,22 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   //   C = [sumA]/(2dt) + cq*dQ                 + kc0
   //   M = [sumQ]/(2dt) + cq*d(Q^2/A)           + kc1 + (g*hth*sumA + kc2)*(cq*dY + hth*sumSe + kc3)     (kc2 carries g)
   // Node s0 + M is lane + 1's node s0 (both lanes hold bitwise equal copies of its unknowns): with one wave per reach the
-  // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding row ever looks at
-  // (and discards) unless the reach fills the wave exactly - then lane 63 evaluates its last node itself.
+  // neighbour's terms arrive by a wave rotate.  Lane 63 receives lane 0's, which only a padding row or the downstream boundary
+  // row ever looks at (and discards): the lane grid holds N rows, so lane 63's last row is never a cell, and its node M is a
+  // clamped copy beyond the reach.  (Until round 3 lane 63 evaluated that node itself whenever the reach filled the wave - a
+  // whole section evaluation per iteration, executed by 64 lanes for a result nobody read: a quarter of the polyline ensemble's
+  // instructions.)
   constexpr bool kShareNode = FS_SHARE_NODE && W == 1 && !Geo::kConstT;
   auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) {
     auto rol = [](R v) { return dpp_mov<0x134>(v); };     // wave_rol:1
     NodeTerms<R> r;
     r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eAT = rol(first.eAT); r.eQ = rol(first.eQ); r.v = rol(first.v);
     r.rT = rol(first.rT);
-    if (NC >= 64 * M - 1 && lane == 63) r = terms_at(M, hM, QM);
+    // (kept for the kernels with more than two rows per lane, where it is one evaluation in M + 1: the (8, 1) polyline kernel
+    // compiled without it fails its fixture although a 13-node reach never takes this branch - like its (8, 4) sibling, see
+    // fs_entries.hpp; unexplained, so the working code stays)
+    if constexpr (M > 2) { if (NC >= 64 * M - 1 && lane == 63) r = terms_at(M, hM, QM); }
+    (void)hM; (void)QM;
     return r;
   };
   auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
@@ -1205,7 +1210,7 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
         const size_t po = (size_t)reach * a.poly_reach_stride, no = a.poly_reach_stride ? (size_t)reach * a.N : 0;
         if (a.poly_n[no + node] > 0) {
           pnode[e].x = a.poly_x + po + node; pnode[e].z = a.poly_z + po + node; pnode[e].stride = a.N; pnode[e].n = a.poly_n[no + node];
-          pnode[e].tz = nullptr; pnode[e].tc = nullptr; pnode[e].ts = nullptr; pnode[e].K = 0;
+          pnode[e].tz = nullptr; pnode[e].K = 0; pnode[e].KP = 0;
         }
       }
     } else {

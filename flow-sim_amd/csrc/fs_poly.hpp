@@ -39,11 +39,14 @@ template <typename R> struct PolyNode {
   const R *x, *z;
   int stride, n;
   R nl, nm, nr, liml, limr, curv, zmin;
-  // stage table of the node (fs_abi.hip: build_stage_table), same vertex-major layout; tz == nullptr: no table, walk the edges
-  const R *tz;             // [K + 1] breakpoints: the distinct vertex elevations, ascending, padded with +inf
-  const R *tc;             // [K][FS_PT_NCOEF] coefficients of interval k = (tz[k], tz[k + 1]] in u = stage - tz[k]
-  const int32_t *ts;       // [K] wetted runs of >= 2 vertices in interval k (get_subchannels, cross_section.py:330-370)
-  int K;
+  // stage table of the node (fs_abi.hip: build_stage_table), one contiguous 16-byte aligned block per node - a lane fetches its
+  // own breakpoints and the coefficients of its own interval with 16-byte loads from two or three cache lines (a first,
+  // vertex-major layout took one 8-byte gather per number: 40 load instructions per node evaluation, each touching up to 64
+  // cache lines - the kernel then waited on the texture path for 63 % of its cycles).  tz == nullptr: no table, walk the edges.
+  const R *tz;             // [KP] breakpoints: the distinct vertex elevations, ascending, padded with +inf (KP even), followed by
+                           // [K][FS_PT_BLOCK] per interval k = (tz[k], tz[k + 1]]: FS_PT_NCOEF coefficients in u = stage - tz[k], then
+                           // the number of wetted runs of >= 2 vertices (get_subchannels, cross_section.py:330-370) as a double
+  int K, KP;
 };
 
 // Stage table.  Between two consecutive vertex elevations the set of wet vertices is fixed, and what properties() /
@@ -53,7 +56,11 @@ template <typename R> struct PolyNode {
 // (zw: elevation of its wet end).  Expanded in u = s - tz[k] >= 0 every coefficient is a sum of non-negative terms - no
 // cancellation, so the 1e-6 finite differences of dR_dA / dA_dh (:523-538) survive.  Per interval: whole section A (3), P (2),
 // T (2), then A (3) and P (2) of the left, main and right roughness strips (an edge belongs to a strip by its two stations, :459).
-enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1, FS_PT_STRIP = 7, FS_PT_NCOEF = 22 };
+enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1, FS_PT_STRIP = 7, FS_PT_NCOEF = 22, FS_PT_NSUB = 22, FS_PT_BLOCK = 24 };
+// doubles of one node's stage table for polylines of up to P vertices
+// (the breakpoints padded with +inf to a multiple of 16: the scan fetches them 16 at a time, eight 16-byte loads in flight)
+__host__ __device__ constexpr int poly_table_bp(int P) { return (P + 16) & ~15; }
+__host__ __device__ constexpr int poly_table_stride(int P) { return poly_table_bp(P) + P * FS_PT_BLOCK; }
 
 // vertices [lo, hi] of a node, optionally extended by a water's-edge point at elevation zc on
 // either side (the x_seg / z_seg of cross_section.py:352-365)
@@ -104,8 +111,10 @@ template <typename R>
 __device__ FS_POLY_ATTR PolySums<R> poly_sums_walk(const PolyNode<R> nd, const PolyView<R> v, R hw) {
   const R dh = R(1e-6);
   const int j0 = v.lo - (v.vl ? 1 : 0), j1 = v.hi + (v.vr ? 1 : 0);
-  auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : nd.x[(size_t)j * nd.stride]); };
-  auto Z = [&](int j) { return (j < v.lo || j > v.hi) ? v.zc : nd.z[(size_t)j * nd.stride]; };
+  typedef const __attribute__((address_space(1))) R *GlobalR;          // (device memory: global loads, not flat ones)
+  const GlobalR gx = (GlobalR)nd.x, gz = (GlobalR)nd.z;
+  auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : gx[(size_t)j * nd.stride]); };
+  auto Z = [&](int j) { return (j < v.lo || j > v.hi) ? v.zc : gz[(size_t)j * nd.stride]; };
   const R xa = X(j0), xb = X(j1);             // self.x[0], self.x[-1] of this (sub-)section
   R A0 = 0, P0 = 0, T0 = 0, A1 = 0, P1 = 0, A2 = 0, P2 = 0, Td = 0;
   R Al = 0, Pl = 0, Am = 0, Pm = 0, Ar = 0, Pr = 0;
@@ -190,55 +199,53 @@ __device__ __noinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R
 }
 
 template <typename R>
-__device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, int *nsub, int *kcache = nullptr) {
+__device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, int *nsub) {
   *nsub = -1;                                   // unknown: the caller counts the runs
   if (nd.tz == nullptr) return poly_eval_whole_walk(nd, hw);
+  typedef R R2 __attribute__((ext_vector_type(2)));
+  // the tables live in device memory: say so (the pointer came through a struct and a call boundary, the compiler no longer
+  // knows, and a flat load waits on the LDS counter as well as on the memory one)
+  typedef const __attribute__((address_space(1))) R2 *GlobalR2;
+  typedef const __attribute__((address_space(1))) R *GlobalR;
   const R dh = R(1e-6);
   const R s1 = hw - dh, s2 = hw + dh;
-  int c0 = 0, c1 = 0, c2 = 0;
-  // a node's stage moves little from one Newton iteration to the next: a caller may keep the interval of its last evaluation;
-  // two loads then confirm that all three stages still lie strictly inside it and stand in for the scan.  (Measured on the
-  // polyline ensemble with the three intervals of a lane kept in registers: 1.35e7 -> 1.31e7 - the kernel sits on its 256-register
-  // cap and the three integers cost more in spills than the 13 loads they save; no caller passes a cache today.)
-  bool hit = false;
-  if (kcache != nullptr && *kcache >= 0) {
-    const int k = *kcache;
-    hit = nd.tz[(size_t)k * nd.stride] < s1 && s2 < nd.tz[(size_t)(k + 1) * nd.stride];
-    c0 = c1 = c2 = k + 1;
+  // One scan places all three stages: c1 = breakpoints below hw - dh, c2 = breakpoints at or below hw + dh.  Equal counts: the
+  // three stages lie strictly inside one interval.  Otherwise a vertex elevation lies within 1e-6 of the stage - or coincides
+  // with a stage to the last bit, where the reference drops the two edges at that vertex (:262) - and the evaluation goes back
+  // to the edge walk (a chance of ~1e-5 per evaluation).
+  int c1 = 0, c2 = 0;
+  const GlobalR2 bp = (GlobalR2)nd.tz;
+  for (int j0 = 0; j0 < nd.KP / 2; j0 += 8) {          // 16 breakpoints per round: all eight loads issued before the first compare
+    R2 z[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = bp[j0 + i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c1 += (z[i].x < s1) + (z[i].y < s1); c2 += (z[i].x <= s2) + (z[i].y <= s2); }
   }
-  if (!hit) {
-    c0 = c1 = c2 = 0;
-    bool exact = false;
-    for (int j = 0; j < nd.K; ++j) {
-      const R zb = nd.tz[(size_t)j * nd.stride];
-      c0 += zb < hw; c1 += zb < s1; c2 += zb < s2;
-      exact = exact || zb == hw || zb == s1 || zb == s2;
-    }
-    if (exact) return poly_eval_whole_walk(nd, hw);
-    if (kcache != nullptr) *kcache = c0 - 1;
-  }
+  if (c1 != c2) return poly_eval_whole_walk(nd, hw);
   PolySums<R> q;
   q.A0 = q.P0 = q.T0 = q.A1 = q.P1 = q.A2 = q.P2 = q.Al = q.Pl = q.Am = q.Pm = q.Ar = q.Pr = R(0);
   *nsub = 0;
-  if (c2 > 0) {
-    auto co = [&](int k, int i) { return nd.tc[((size_t)k * FS_PT_NCOEF + i) * nd.stride]; };
-    auto zk = [&](int k) { return nd.tz[(size_t)k * nd.stride]; };
-    auto area = [&](int k, R u) { return fma_(fma_(co(k, FS_PT_A2), u, co(k, FS_PT_A1)), u, co(k, FS_PT_A0)); };
-    auto peri = [&](int k, R u) { return fma_(co(k, FS_PT_P1), u, co(k, FS_PT_P0)); };
-    if (c0 > 0) {
-      const int k = c0 - 1;
-      const R u = hw - zk(k);
-      q.A0 = area(k, u); q.P0 = peri(k, u); q.T0 = fma_(co(k, FS_PT_T1), u, co(k, FS_PT_T0));
-      auto strip = [&](int sidx, R &A, R &P) {
-        const int o = FS_PT_STRIP + 5 * sidx;
-        A = fma_(fma_(co(k, o + 2), u, co(k, o + 1)), u, co(k, o));
-        P = fma_(co(k, o + 4), u, co(k, o + 3));
-      };
-      strip(0, q.Al, q.Pl); strip(1, q.Am, q.Pm); strip(2, q.Ar, q.Pr);
-      *nsub = nd.ts[(size_t)k * nd.stride];
-    }
-    if (c1 > 0) { const int k = c1 - 1; const R u = s1 - zk(k); q.A1 = area(k, u); q.P1 = peri(k, u); }
-    { const int k = c2 - 1; const R u = s2 - zk(k); q.A2 = area(k, u); q.P2 = peri(k, u); }
+  if (c1 > 0) {
+    const int k = c1 - 1;
+    const GlobalR2 cb = (GlobalR2)(nd.tz + nd.KP + (size_t)k * FS_PT_BLOCK);
+    const R zk = ((GlobalR)nd.tz)[k];
+    R co[FS_PT_BLOCK];
+#pragma unroll
+    for (int i = 0; i < FS_PT_BLOCK / 2; ++i) { const R2 v = cb[i]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
+    const R u = hw - zk, u1 = s1 - zk, u2 = s2 - zk;
+    q.A0 = fma_(fma_(co[FS_PT_A2], u, co[FS_PT_A1]), u, co[FS_PT_A0]);
+    q.P0 = fma_(co[FS_PT_P1], u, co[FS_PT_P0]);
+    q.T0 = fma_(co[FS_PT_T1], u, co[FS_PT_T0]);
+    q.A1 = fma_(fma_(co[FS_PT_A2], u1, co[FS_PT_A1]), u1, co[FS_PT_A0]); q.P1 = fma_(co[FS_PT_P1], u1, co[FS_PT_P0]);
+    q.A2 = fma_(fma_(co[FS_PT_A2], u2, co[FS_PT_A1]), u2, co[FS_PT_A0]); q.P2 = fma_(co[FS_PT_P1], u2, co[FS_PT_P0]);
+    auto strip = [&](int sidx, R &A, R &P) {
+      const int o = FS_PT_STRIP + 5 * sidx;
+      A = fma_(fma_(co[o + 2], u, co[o + 1]), u, co[o]);
+      P = fma_(co[o + 4], u, co[o + 3]);
+    };
+    strip(0, q.Al, q.Pl); strip(1, q.Am, q.Pm); strip(2, q.Ar, q.Pr);
+    *nsub = (int)co[FS_PT_NSUB];
   }
   return poly_finish(nd, q);
 }
@@ -246,17 +253,19 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, 
 // Se, dSe/dA, dSe/dQ, A, dA/dh of a polyline node: friction_slope / dSf_dA / dSf_dQ of
 // cross_section.py:372-447 (sub-channel sum when >= 2 wetted runs) plus the base-class curvature terms.
 template <typename R>
-__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q, int *kcache = nullptr) {
+__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
   const R hw = h + nd.zmin;
   int nsub = 0;
-  const PolyEval<R> e = poly_eval_whole(nd, hw, &nsub, kcache);
+  const PolyEval<R> e = poly_eval_whole(nd, hw, &nsub);
   R K = e.K, dK = e.dKdA;
   // wetted runs of >= 2 vertices (get_subchannels, :330-370): from the stage table, else counted here
+  typedef const __attribute__((address_space(1))) R *GlobalR;
+  const GlobalR gx = (GlobalR)nd.x, gz = (GlobalR)nd.z;
   if (nsub < 0) {
     nsub = 0;
     int run = 0;
     for (int j = 0; j < nd.n; ++j) {
-      const bool wet = nd.z[(size_t)j * nd.stride] < hw;
+      const bool wet = gz[(size_t)j * nd.stride] < hw;
       if (wet) ++run;
       if (!wet || j == nd.n - 1) { nsub += run >= 2; run = 0; }
     }
@@ -265,20 +274,20 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
     R Ks = 0, dKs = 0;
     int s = -1;
     for (int j = 0; j <= nd.n; ++j) {
-      const bool wet = j < nd.n && nd.z[(size_t)j * nd.stride] < hw;
+      const bool wet = j < nd.n && gz[(size_t)j * nd.stride] < hw;
       if (wet && s < 0) s = j;
       if (!wet && s >= 0) {
         const int en = j;                                   // one past the last wet vertex
         if (en - s >= 2) {
           PolyView<R> v;
           v.lo = s; v.hi = en - 1; v.zc = hw;
-          v.vl = s > 0 && nd.z[(size_t)(s - 1) * nd.stride] > hw;
-          v.xl = nd.x[(size_t)s * nd.stride];               // :357 (np.interp, decreasing abscissa)
+          v.vl = s > 0 && gz[(size_t)(s - 1) * nd.stride] > hw;
+          v.xl = gx[(size_t)s * nd.stride];               // :357 (np.interp, decreasing abscissa)
           v.vr = false; v.xr = R(0);
           if (en < nd.n) {
-            const R za = nd.z[(size_t)(en - 1) * nd.stride], zb = nd.z[(size_t)en * nd.stride];
+            const R za = gz[(size_t)(en - 1) * nd.stride], zb = gz[(size_t)en * nd.stride];
             if (za < hw && zb > hw) {                       // :360-363
-              const R xa_ = nd.x[(size_t)(en - 1) * nd.stride], xb_ = nd.x[(size_t)en * nd.stride];
+              const R xa_ = gx[(size_t)(en - 1) * nd.stride], xb_ = gx[(size_t)en * nd.stride];
               v.vr = true;
               v.xr = (xb_ - xa_) / (zb - za) * (hw - za) + xa_;
             }
