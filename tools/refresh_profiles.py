@@ -54,6 +54,11 @@ out = {"tag": a.tag, "source": f"rocprofv3 passes of tools/profile.sh {a.tag} " 
        "kernel": cfg["kernel"], "nodes": N, "reaches": B, "levels_in_launch": K, "dtype": bench["dtype"],
        "mean_newton_iterations_per_step": its,
        "kernel_stats_avg_ns": float(krow["AverageNs"]), "kernel_stats_calls": int(krow["Calls"]),
+       "kernel_stats_max_ns": float(krow["MaxNs"]), "kernel_stats_total_ns": float(krow["TotalDurationNs"]),
+       "kernel_stats_note": f"{krow['Calls']} launches in the trace: the warm-up launch ({bench['warmup']} levels) and the timed launch "
+                            f"({K} levels) - the timed one is MaxNs; per level, TotalDurationNs / {bench['warmup'] + K} levels "
+                            f"= {float(krow['TotalDurationNs']) / (bench['warmup'] + K) / 1e6:.4f} ms against bench.py's "
+                            f"{bench['roofline']['kernel_ms'] / K:.4f} ms",
        "bench_kernel_ms": bench["roofline"]["kernel_ms"], "bench_value": bench["value"]}
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     fetch_raw, write = vals["FETCH_SIZE"] * 1024, vals["WRITE_SIZE"] * 1024
