@@ -101,6 +101,7 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
 const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND))
+                          FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, true)
@@ -643,8 +644,10 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 // vertex so that no lane ever reads NaN).  Returns an error text or nullptr.
 // Stage table of one polyline (fs_poly.hpp): breakpoints = the distinct vertex elevations; for each interval between two of
 // them the polynomial coefficients of A, P, T and of the three roughness strips' (A, P) in u = stage - lower breakpoint, and
-// the number of wetted runs of >= 2 vertices.  One contiguous block per node: [KP] breakpoints, then [P][FS_PT_BLOCK].
-static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, int P, double *blk) {
+// the number of wetted runs of >= 2 vertices.  One contiguous block per node: [KP] breakpoints, then [P][FS_PT_BLOCK]
+// (each interval's block also carries its bounds and the node's constants).
+static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, int P, double *blk,
+                              const double node_const[5] /* n_left, n_main, n_right, curvature, z_min */) {
   std::vector<double> lev(zs, zs + c);
   std::sort(lev.begin(), lev.end());
   lev.erase(std::unique(lev.begin(), lev.end()), lev.end());
@@ -689,6 +692,9 @@ static void build_stage_table(const double *xs, const double *zs, int c, double 
       }
     }
     co[fs::FS_PT_NSUB] = (double)runs;
+    // what an evaluation that starts from this interval needs besides the coefficients (fs_poly.hpp: node_terms_poly_hinted)
+    co[fs::FS_PT_ZLO] = k < K ? lev[k] : inf; co[fs::FS_PT_ZHI] = k + 1 < K ? lev[k + 1] : inf;
+    for (int q = 0; q < 5; ++q) co[fs::FS_PT_NL + q] = node_const[q];
   }
 }
 
@@ -713,7 +719,10 @@ static const char *pack_polylines(const double *table, const int32_t *n_pts, int
       xt[j * N + i] = x[src]; zt[j * N + i] = z[src];
     }
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
-    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], max_pts, tz + i * (size_t)fs::poly_table_stride(max_pts));
+    const double node_const[5] = {table[(size_t)FS_GEO_N_LEFT * N + i], table[(size_t)FS_GEO_N_MAIN * N + i],
+                                  table[(size_t)FS_GEO_N_RIGHT * N + i], table[(size_t)FS_GEO_CURVATURE * N + i], zmin};
+    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], max_pts, tz + i * (size_t)fs::poly_table_stride(max_pts),
+                      node_const);
   }
   return nullptr;
 }

@@ -46,6 +46,12 @@
 #ifndef FS_SAVE_TERMS
 #define FS_SAVE_TERMS 1
 #endif
+#ifndef FS_POLY_HINT
+#define FS_POLY_HINT 1     // polyline nodes start from the stage-table interval of their last evaluation (fs_poly.hpp)
+#endif
+#ifndef FS_POLY_SLOW_INLINE
+#define FS_POLY_SLOW_INLINE 1   // the scan / edge-walk path behind the hinted evaluation inline too (out of line: -6 % on the polyline ensemble, the call pins registers)
+#endif
 #ifndef FS_SHARE_NODE
 #define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
 #endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
@@ -350,6 +356,26 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     if (((const __attribute__((address_space(1))) int32_t *)pn)[node] > 0) return node_terms_poly(poly(node), h, Q);
     return node_terms_general_call(section(node), h, Q);
   }
+  // The same starting from the table interval of the node's last evaluation (fs_poly.hpp: node_terms_poly_hinted).  kh is the
+  // caller's per-row hint: -2 a node without a polyline, -1 nothing to start from, >= 0 the interval.
+  __device__ __forceinline__ int hint_init(int node) const {
+    return ((const __attribute__((address_space(1))) int32_t *)pn)[node] > 0 ? -1 : -2;
+  }
+#if FS_POLY_SLOW_INLINE
+  __device__ __forceinline__
+#else
+  __device__ __noinline__
+#endif
+  static TermsHint<R> terms_scan(const Geometry g, int node, R h, R Q) {
+    TermsHint<R> r;
+    r.t = node_terms_poly(g.poly(node), h, Q, &r.k, &r.bc);
+    return r;
+  }
+  __device__ __forceinline__ NodeTerms<R> terms_hinted(int node, R h, R Q, int &kh, PolyBC<R> &bc) const {
+    if (kh == -2) return node_terms_general_call(section(node), h, Q);
+    return node_terms_poly_hinted(ptz + (size_t)node * poly_table_stride(pK), poly_table_bp(pK), tb.has_over, tb.n_over, kh, h, Q, bc,
+                                  [&]() { return terms_scan(*this, node, h, Q); });
+  }
   // the same out of line: the kernels with many rows per lane evaluate 2 (M + 1) nodes per iteration - inlined, the polyline
   // code made them ~30 000 instructions long (and the 4-wave one of them miscompiled); two rows per lane keep it inline (+37 %)
   __device__ __noinline__ NodeTerms<R> terms_call(int node, R h, R Q) const { return terms(node, h, Q); }
@@ -451,8 +477,20 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #pragma unroll
     for (int j = 0; j <= M; ++j) secs[j] = geo.section(min(s0 + j, N - 1));
   }
+  // polyline nodes: the stage-table interval each of the lane's nodes was last evaluated in (Geometry::terms_hinted)
+  constexpr bool kHinted = SEC == FS_SEC_IRREGULAR && M <= 2 && FS_POLY_HINT;
+  int khint[kHinted ? M + 1 : 1];
+  PolyBC<R> polybc[kHinted ? M + 1 : 1];      // (K, dK/dA, dA/dh) of the lane's nodes as last evaluated: the fused normal-depth row below
+  if constexpr (kHinted) {
+#pragma unroll
+    for (int j = 0; j <= M; ++j) {
+      khint[j] = geo.hint_init(min(s0 + j, N - 1));
+      polybc[j].K = R(0); polybc[j].dKdA = R(0); polybc[j].dAdh = R(0);
+    }
+  }
   auto terms_at = [&](int j, R hh, R QQ) {
     if constexpr (kRegGeo) return node_terms_general(secs[j], hh, QQ);
+    else if constexpr (kHinted) return geo.terms_hinted(min(s0 + j, N - 1), hh, QQ, khint[j], polybc[j]);
     else if constexpr (SEC == FS_SEC_IRREGULAR && M > 2) return geo.terms_call(min(s0 + j, N - 1), hh, QQ);
     else return geo.terms(min(s0 + j, N - 1), hh, QQ);
   };
@@ -576,6 +614,21 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   if (usd.kind <= FS_BC_STORAGE) { usd.params = &sm.bcp[0][0]; usd.stride = 0; }
   if (dsd.kind <= FS_BC_STORAGE) { dsd.params = &sm.bcp[1][0]; dsd.stride = 0; }
 
+  // Normal depth at a polyline node N-1 whose boundary bed level is the section's own z_min (boundary.py:80, :161-181 then
+  // evaluate residual and derivative at the same stage): the row is K, dK/dA, dA/dh of node N-1 at the iterate - exactly what
+  // the fold's evaluation of that node has just produced.  The row is then written in the fold, from that evaluation, and the
+  // boundary's own section evaluation (a whole wave waiting on one lane: three dependent fetches and ~600 instructions per
+  // Newton iteration, a third of the polyline ensemble's time) is not made.
+  bool fuseD = false;
+  R fuse_sg = R(1), fuse_rt = R(0);
+  if constexpr (kHinted && !kFlatBC) {
+    __syncthreads();                                    // (sm.bcp written above)
+    if (pinned<BCK, 1>(dsd).kind == FS_BC_NORMAL_DEPTH && geo.hint_init(N - 1) != -2 && sm.bcp[1][1] == geo.bed(N - 1)) {
+      fuseD = true;
+      const R S0 = sm.bcp[1][0];
+      fuse_sg = S0 < R(0) ? R(-1) : R(1); fuse_rt = sqrt_(fabs_(S0));
+    }
+  }
   // a compile-time constant in the kernels compiled for a boundary pair
   const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(dsd.kind);
   R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
@@ -685,7 +738,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
           nrm2 = Urow.res * Urow.res;
         }
-        if (t == tD) {
+        if (t == tD && !fuseD) {
           R hD = h[0], QD = Q[0];
           int flag = 0;
 #pragma unroll
@@ -748,10 +801,17 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
               const bool cell = RAGGED ? (k < NC) : (t != T - 1);
               const bool bcr = RAGGED ? (k == NC) : true;
               if (!cell) {
-                const R x = Drow.dh * i2tL, y = Drow.dq * i2c;
-                row.al = bcr ? x + y : R(0); row.D = bcr ? x - y : R(1); row.de = R(0);
-                row.rho0 = bcr ? -Drow.res : R(0); row.rc = R(0);
+                BCRow<R> Dr = Drow;
                 r2 = R(0);
+                if constexpr (kHinted) {
+                  if (fuseD) {                 // normal depth from the fold's own evaluation of node N-1 (= the row's left node)
+                    Dr = normal_depth_row_poly(fuse_sg, fuse_rt, polybc[c].K, polybc[c].dKdA, polybc[c].dAdh, Q[c]);
+                    r2 = bcr ? Dr.res * Dr.res : R(0);
+                  }
+                }
+                const R x = Dr.dh * i2tL, y = Dr.dq * i2c;
+                row.al = bcr ? x + y : R(0); row.D = bcr ? x - y : R(1); row.de = R(0);
+                row.rho0 = bcr ? -Dr.res : R(0); row.rc = R(0);
               }
             }
             nrm2 += r2;

@@ -56,7 +56,12 @@ template <typename R> struct PolyNode {
 // (zw: elevation of its wet end).  Expanded in u = s - tz[k] >= 0 every coefficient is a sum of non-negative terms - no
 // cancellation, so the 1e-6 finite differences of dR_dA / dA_dh (:523-538) survive.  Per interval: whole section A (3), P (2),
 // T (2), then A (3) and P (2) of the left, main and right roughness strips (an edge belongs to a strip by its two stations, :459).
-enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1, FS_PT_STRIP = 7, FS_PT_NCOEF = 22, FS_PT_NSUB = 22, FS_PT_BLOCK = 24 };
+// An interval's block then carries what an evaluation inside it needs and nothing else has to be fetched: its own bounds (the
+// next evaluation of the node starts from the interval of the last one, node_terms_poly_hinted), the node's three Manning
+// values, its curvature and z_min.  32 doubles = two 128-byte lines, fetched with sixteen 16-byte loads off one address.
+enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1, FS_PT_STRIP = 7, FS_PT_NCOEF = 22, FS_PT_NSUB = 22,
+       FS_PT_ZLO = 23, FS_PT_ZHI = 24, FS_PT_NL = 25, FS_PT_NM = 26, FS_PT_NR = 27, FS_PT_CURV = 28, FS_PT_ZMIN = 29, FS_PT_USED = 30,
+       FS_PT_BLOCK = 32 };
 // doubles of one node's stage table for polylines of up to P vertices
 // (the breakpoints padded with +inf to a multiple of 16: the scan fetches them 16 at a time, eight 16-byte loads in flight)
 __host__ __device__ constexpr int poly_table_bp(int P) { return (P + 16) & ~15; }
@@ -67,6 +72,9 @@ __host__ __device__ constexpr int poly_table_stride(int P) { return poly_table_b
 template <typename R> struct PolyView { int lo, hi; bool vl, vr; R xl, xr, zc; };
 
 template <typename R> struct PolyEval { R A, P, Rh, T, neq, K, dRdA, dKdA, dAdh, y13; };
+// (K, dK/dA, dA/dh of the WHOLE section ride along: a normal-depth boundary at the node is a row in these three,
+// boundary.py:80, :161-181, and the kernel takes it from the fold's own evaluation of the node instead of evaluating twice)
+template <typename R> struct PolyBC { R K, dKdA, dAdh; };
 
 // sqrt that tolerates 0 (a vertical or degenerate edge): x / sqrt(x) via the reciprocal square root
 template <typename R> __device__ __forceinline__ R fsqrt_len(R x) { return x > R(0) ? fsqrt_pos(x) : R(0); }
@@ -198,15 +206,47 @@ __device__ __noinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R
   return poly_finish(nd, poly_sums_walk(nd, poly_whole(nd), hw));
 }
 
+// (A, P) at the three stages, T and the strips' (A, P) at hw from the coefficients of the interval that holds them (zk: its
+// lower breakpoint)
 template <typename R>
-__device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, int *nsub) {
+__device__ __forceinline__ PolySums<R> poly_sums_table(const R (&co)[FS_PT_USED], R zk, R hw) {
+  const R dh = R(1e-6);
+  const R u = hw - zk, u1 = (hw - dh) - zk, u2 = (hw + dh) - zk;
+  PolySums<R> q;
+  q.A0 = fma_(fma_(co[FS_PT_A2], u, co[FS_PT_A1]), u, co[FS_PT_A0]);
+  q.P0 = fma_(co[FS_PT_P1], u, co[FS_PT_P0]);
+  q.T0 = fma_(co[FS_PT_T1], u, co[FS_PT_T0]);
+  q.A1 = fma_(fma_(co[FS_PT_A2], u1, co[FS_PT_A1]), u1, co[FS_PT_A0]); q.P1 = fma_(co[FS_PT_P1], u1, co[FS_PT_P0]);
+  q.A2 = fma_(fma_(co[FS_PT_A2], u2, co[FS_PT_A1]), u2, co[FS_PT_A0]); q.P2 = fma_(co[FS_PT_P1], u2, co[FS_PT_P0]);
+  auto strip = [&](int sidx, R &A, R &P) {
+    const int o = FS_PT_STRIP + 5 * sidx;
+    A = fma_(fma_(co[o + 2], u, co[o + 1]), u, co[o]);
+    P = fma_(co[o + 4], u, co[o + 3]);
+  };
+  strip(0, q.Al, q.Pl); strip(1, q.Am, q.Pm); strip(2, q.Ar, q.Pr);
+  return q;
+}
+
+// the block of interval k of a node's stage table (tz: the node's table, KP breakpoints ahead of the blocks)
+template <typename R>
+__device__ __forceinline__ void poly_load_block(const R *tz, int KP, int k, R (&co)[FS_PT_USED]) {
+  typedef R R2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(1))) R2 *GlobalR2;
+  const GlobalR2 cb = (GlobalR2)(tz + KP + (size_t)k * FS_PT_BLOCK);
+#pragma unroll
+  for (int i = 0; i < FS_PT_USED / 2; ++i) { const R2 v = cb[i]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
+}
+
+// *kout (optional): the interval the stage was found in, -1 when the evaluation went back to the edge walk
+template <typename R>
+__device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, int *nsub, int *kout = nullptr) {
   *nsub = -1;                                   // unknown: the caller counts the runs
+  if (kout) *kout = -1;
   if (nd.tz == nullptr) return poly_eval_whole_walk(nd, hw);
   typedef R R2 __attribute__((ext_vector_type(2)));
   // the tables live in device memory: say so (the pointer came through a struct and a call boundary, the compiler no longer
   // knows, and a flat load waits on the LDS counter as well as on the memory one)
   typedef const __attribute__((address_space(1))) R2 *GlobalR2;
-  typedef const __attribute__((address_space(1))) R *GlobalR;
   const R dh = R(1e-6);
   const R s1 = hw - dh, s2 = hw + dh;
   // One scan places all three stages: c1 = breakpoints below hw - dh, c2 = breakpoints at or below hw + dh.  Equal counts: the
@@ -227,36 +267,41 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, 
   q.A0 = q.P0 = q.T0 = q.A1 = q.P1 = q.A2 = q.P2 = q.Al = q.Pl = q.Am = q.Pm = q.Ar = q.Pr = R(0);
   *nsub = 0;
   if (c1 > 0) {
-    const int k = c1 - 1;
-    const GlobalR2 cb = (GlobalR2)(nd.tz + nd.KP + (size_t)k * FS_PT_BLOCK);
-    const R zk = ((GlobalR)nd.tz)[k];
-    R co[FS_PT_BLOCK];
-#pragma unroll
-    for (int i = 0; i < FS_PT_BLOCK / 2; ++i) { const R2 v = cb[i]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
-    const R u = hw - zk, u1 = s1 - zk, u2 = s2 - zk;
-    q.A0 = fma_(fma_(co[FS_PT_A2], u, co[FS_PT_A1]), u, co[FS_PT_A0]);
-    q.P0 = fma_(co[FS_PT_P1], u, co[FS_PT_P0]);
-    q.T0 = fma_(co[FS_PT_T1], u, co[FS_PT_T0]);
-    q.A1 = fma_(fma_(co[FS_PT_A2], u1, co[FS_PT_A1]), u1, co[FS_PT_A0]); q.P1 = fma_(co[FS_PT_P1], u1, co[FS_PT_P0]);
-    q.A2 = fma_(fma_(co[FS_PT_A2], u2, co[FS_PT_A1]), u2, co[FS_PT_A0]); q.P2 = fma_(co[FS_PT_P1], u2, co[FS_PT_P0]);
-    auto strip = [&](int sidx, R &A, R &P) {
-      const int o = FS_PT_STRIP + 5 * sidx;
-      A = fma_(fma_(co[o + 2], u, co[o + 1]), u, co[o]);
-      P = fma_(co[o + 4], u, co[o + 3]);
-    };
-    strip(0, q.Al, q.Pl); strip(1, q.Am, q.Pm); strip(2, q.Ar, q.Pr);
+    R co[FS_PT_USED];
+    poly_load_block(nd.tz, nd.KP, c1 - 1, co);
+    q = poly_sums_table(co, co[FS_PT_ZLO], hw);
     *nsub = (int)co[FS_PT_NSUB];
+    if (kout) *kout = c1 - 1;
   }
   return poly_finish(nd, q);
 }
 
 // Se, dSe/dA, dSe/dQ, A, dA/dh of a polyline node: friction_slope / dSf_dA / dSf_dQ of
 // cross_section.py:372-447 (sub-channel sum when >= 2 wetted runs) plus the base-class curvature terms.
+// the node terms from the section's properties and its conveyance (K, dK/dA: the whole section's or the sub-channel sums)
 template <typename R>
-__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q) {
+__device__ __forceinline__ NodeTerms<R> poly_terms_tail(const PolyEval<R> &e, R K, R dK, R curv, R h, R Q) {
+  NodeTerms<R> t;
+  const R rK = frcp(K), iK2 = rK * rK;
+  const R aQ = fabs_(Q);
+  const R Sf = Q * aQ * iK2;
+  R dSeA = R(-2) * Sf * (dK * rK);
+  R Se = Sf, eQ = R(2) * aQ * iK2;
+  add_curvature(curv, e.A, frcp(e.A), e.T, frcp(e.T), e.dAdh, e.neq, e.y13, e.dRdA, h, Q, Se, dSeA, eQ);
+  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eAT = dSeA; t.eQ = eQ; t.v = Q * frcp(e.A);
+  t.rT = frcp(e.dAdh);
+  return t;
+}
+
+// *kout (optional): the table interval the evaluation used when a later one may start from it (one wetted run, no edge walk),
+// else -1
+template <typename R>
+__device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, R Q, int *kout = nullptr, PolyBC<R> *bc = nullptr) {
   const R hw = h + nd.zmin;
   int nsub = 0;
-  const PolyEval<R> e = poly_eval_whole(nd, hw, &nsub);
+  const PolyEval<R> e = poly_eval_whole(nd, hw, &nsub, kout);
+  if (kout && nsub >= 2) *kout = -1;
+  if (bc) { bc->K = e.K; bc->dKdA = e.dKdA; bc->dAdh = e.dAdh; }
   R K = e.K, dK = e.dKdA;
   // wetted runs of >= 2 vertices (get_subchannels, :330-370): from the stage table, else counted here
   typedef const __attribute__((address_space(1))) R *GlobalR;
@@ -302,20 +347,48 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
     K = p23_(Ks);                                           // :392, :415
     dK = R(2.0 / 3.0) * rcbrt_pos(Ks) * dKs;                // :416
   }
-  NodeTerms<R> t;
-  const R rK = frcp(K), iK2 = rK * rK;
-  const R aQ = fabs_(Q);
-  const R Sf = Q * aQ * iK2;
-  R dSeA = R(-2) * Sf * (dK * rK);
-  R Se = Sf, eQ = R(2) * aQ * iK2;
-  add_curvature(nd.curv, e.A, frcp(e.A), e.T, frcp(e.T), e.dAdh, e.neq, e.y13, e.dRdA, h, Q, Se, dSeA, eQ);
-  t.A = e.A; t.T = e.dAdh; t.Se = Se; t.eAT = dSeA; t.eQ = eQ; t.v = Q * frcp(e.A);
-  t.rT = frcp(e.dAdh);
-  return t;
+  return poly_terms_tail(e, K, dK, nd.curv, h, Q);
+}
+
+// The same from the interval of the node's last evaluation.  A Newton iterate moves the stage by far less than the distance
+// between two vertex elevations, so nearly every evaluation finds its stage in the interval the last one used: ONE fetch of
+// that interval's block (it brings the interval's bounds and the node's constants with it, see FS_PT_*), no breakpoint scan, no
+// per-node parameter loads - one memory round trip where the scan path has three in a row (node parameters, breakpoints,
+// coefficients).  Same coefficients, same arithmetic: the result is bitwise that of node_terms_poly.  `slow` is called (with
+// nothing fetched) when there is no interval to start from, when the stage has left it, or when the interval has two or more
+// wetted runs (sub-channels: node_terms_poly walks them); it returns the terms and the next hint.
+template <typename R> struct TermsHint { NodeTerms<R> t; PolyBC<R> bc; int k; };
+
+template <typename R, typename Slow>
+__device__ __forceinline__ NodeTerms<R> node_terms_poly_hinted(const R *tz, int KP, bool has_over, R n_over, int &kh, R h, R Q,
+                                                               PolyBC<R> &bc, Slow slow) {
+  if (kh >= 0) {
+    R co[FS_PT_USED];
+    poly_load_block(tz, KP, kh, co);
+    const R hw = h + co[FS_PT_ZMIN], dh = R(1e-6);
+    if (co[FS_PT_ZLO] < hw - dh && co[FS_PT_ZHI] > hw + dh && co[FS_PT_NSUB] < R(2)) {
+      PolyNode<R> nd;                                      // (poly_finish reads the three Manning values only)
+      nd.nl = co[FS_PT_NL]; nd.nm = has_over ? n_over : co[FS_PT_NM]; nd.nr = co[FS_PT_NR];
+      const PolyEval<R> e = poly_finish(nd, poly_sums_table(co, co[FS_PT_ZLO], hw));
+      bc.K = e.K; bc.dKdA = e.dKdA; bc.dAdh = e.dAdh;
+      return poly_terms_tail(e, e.K, e.dKdA, co[FS_PT_CURV], h, Q);
+    }
+  }
+  const TermsHint<R> r = slow();
+  kh = r.k; bc = r.bc;
+  return r.t;
 }
 
 // normal-depth boundary row at a polyline node: conveyance at hw = z_min + h for the residual,
 // dK/dA * dA/dh at hw = h + bed_level for the derivative (boundary.py:80, :91, :161, :180)
+template <typename R> __device__ __forceinline__ BCRow<R> normal_depth_row_poly(R sg, R rt, R K, R dKdA, R dAdh, R Q) {
+  BCRow<R> r;
+  r.res = Q - sg * K * rt;
+  r.dh = R(0) - sg * dKdA * rt * dAdh;
+  r.dq = R(1);
+  return r;
+}
+
 template <typename R>
 __device__ FS_POLY_ATTR BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0, R bed, R h, R Q) {
   const R sg = S0 < R(0) ? R(-1) : R(1);
@@ -326,11 +399,7 @@ __device__ FS_POLY_ATTR BCRow<R> bc_normal_depth_poly(const PolyNode<R> nd, R S0
   // are usually the same stage, and a section walk here costs the reach's only wave as much as a node of the fold
   PolyEval<R> gd = gr;
   if (h + bed != nd.zmin + h) gd = poly_eval_whole(nd, h + bed, &ns_);
-  BCRow<R> r;
-  r.res = Q - sg * gr.K * rt;
-  r.dh = R(0) - sg * gd.dKdA * rt * gd.dAdh;
-  r.dq = R(1);
-  return r;
+  return normal_depth_row_poly(sg, rt, gr.K, gd.dKdA, gd.dAdh, Q);
 }
 
 // area and geometric top width only (Solver.prepare_results, solver.py:65-127)
