@@ -644,8 +644,8 @@ int fs_batch_set_geometry_table(fs_batch *b, const double *table, const double *
 // vertex so that no lane ever reads NaN).  Returns an error text or nullptr.
 // Stage table of one polyline (fs_poly.hpp): breakpoints = the distinct vertex elevations; for each interval between two of
 // them the polynomial coefficients of A, P, T and of the three roughness strips' (A, P) in u = stage - lower breakpoint, and
-// the number of wetted runs of >= 2 vertices.  One contiguous block per node: [KP] breakpoints, then [P][FS_PT_BLOCK]
-// (each interval's block also carries its bounds and the node's constants).
+// the number of wetted runs of >= 2 vertices.  Built per node as [KP] breakpoints + [P][FS_PT_BLOCK] (each interval's entry also carries its bounds and the node's constants);
+// pack_polylines lays the entries out node-minor for the device.
 static void build_stage_table(const double *xs, const double *zs, int c, double liml, double limr, int P, double *blk,
                               const double node_const[5] /* n_left, n_main, n_right, curvature, z_min */) {
   std::vector<double> lev(zs, zs + c);
@@ -721,8 +721,15 @@ static const char *pack_polylines(const double *table, const int32_t *n_pts, int
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
     const double node_const[5] = {table[(size_t)FS_GEO_N_LEFT * N + i], table[(size_t)FS_GEO_N_MAIN * N + i],
                                   table[(size_t)FS_GEO_N_RIGHT * N + i], table[(size_t)FS_GEO_CURVATURE * N + i], zmin};
-    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], max_pts, tz + i * (size_t)fs::poly_table_stride(max_pts),
-                      node_const);
+    // the node's table, then into the device layout: breakpoints [N][KP], intervals [P][FS_PT_BLOCK / 2][N] pairs (fs_poly.hpp)
+    const size_t KP = fs::poly_table_bp(max_pts);
+    std::vector<double> blk(fs::poly_table_stride(max_pts));
+    build_stage_table(x + i * P, z + i * P, c, limits[2 * i], limits[2 * i + 1], max_pts, blk.data(), node_const);
+    std::memcpy(tz + i * KP, blk.data(), KP * sizeof(double));
+    double *co = tz + N * KP;
+    for (size_t q = 0; q < P * fs::FS_PT_BLOCK; q += 2) {
+      co[((q / 2) * N + i) * 2] = blk[KP + q]; co[((q / 2) * N + i) * 2 + 1] = blk[KP + q + 1];
+    }
   }
   return nullptr;
 }

@@ -182,7 +182,7 @@ template <typename R> struct KernelArgs {
   const int32_t *reach_nodes;    // [B] or nullptr: nodes of each reach (<= N; N stays the row stride of every [B][N] array)
   const R *reach_scheme;         // [3][B] or nullptr: theta, dt, dx of each reach
   const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE)
-  const R *poly_tz;              // IRREGULAR: stage tables (fs_poly.hpp): [N][poly_table_stride(P)], one block per node
+  const R *poly_tz;              // IRREGULAR: stage tables (fs_poly.hpp): breakpoints [N][KP], then intervals [P][16][N] pairs
   int32_t poly_K;                // IRREGULAR: P, intervals per node in the stage tables (0: no tables, walk the edges)
   R *kc_scratch;           // long reaches (fs_long.hpp): [B][4][passes * 64 W M] level constants, owned by the batch
   int32_t passes;          // long reaches: passes of 64 W M rows a workgroup makes over its reach
@@ -331,7 +331,7 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     const bool own = a.poly_reach_stride != 0;
     px = a.poly_x + (size_t)reach * a.poly_reach_stride; pz = a.poly_z + (size_t)reach * a.poly_reach_stride;
     plim = a.poly_lim + (own ? (size_t)reach * 2 * a.N : 0); pn = a.poly_n + (own ? (size_t)reach * a.N : 0);
-    pK = a.poly_K;                                     // stage tables: [N][poly_table_stride(P)] per reach (or shared)
+    pK = a.poly_K;                                     // stage tables: N * poly_table_stride(P) numbers per reach (or shared)
     ptz = pK ? a.poly_tz + (own ? (size_t)reach * a.N * poly_table_stride(pK) : 0) : nullptr;
   }
   __device__ __forceinline__ R terms_T() const { return R(0); }
@@ -339,6 +339,8 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   __device__ __forceinline__ R bed_step(int node) const { return tb.bed_step(node); }
   __device__ __forceinline__ R bed(int node) const { return tb.bed(node); }
   __device__ __forceinline__ SecParams<R> section(int node) const { return tb.section(node); }
+  // the node's slot in the interval part of the stage tables (behind the [N][KP] breakpoints; fs_poly.hpp)
+  __device__ __forceinline__ const R *table_slot(int node) const { return ptz + (size_t)tb.N * poly_table_bp(pK) + 2 * (size_t)node; }
   __device__ __forceinline__ PolyNode<R> poly(int node) const {
     PolyNode<R> p;
     const int N = tb.N;
@@ -349,7 +351,8 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     p.nl = g(FS_GEO_N_LEFT); p.nm = tb.has_over ? tb.n_over : g(FS_GEO_N_MAIN); p.nr = g(FS_GEO_N_RIGHT);
     p.liml = ((GlobalR)plim)[node]; p.limr = ((GlobalR)plim)[N + node];
     p.curv = g(FS_GEO_CURVATURE); p.zmin = g(FS_GEO_Z_BED);
-    p.tz = ptz ? ptz + (size_t)node * poly_table_stride(pK) : nullptr; p.K = pK; p.KP = poly_table_bp(pK);
+    p.K = pK; p.KP = poly_table_bp(pK);
+    p.tz = ptz ? ptz + (size_t)node * p.KP : nullptr; p.tco = ptz ? table_slot(node) : nullptr; p.cstride = N;
     return p;
   }
   __device__ __forceinline__ NodeTerms<R> terms(int node, R h, R Q) const {
@@ -371,10 +374,15 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     r.t = node_terms_poly(g.poly(node), h, Q, &r.k, &r.bc);
     return r;
   }
+  // (The paths beside the hinted one take the node index through an empty asm: everything they derive from it - a dozen row
+  // addresses of the parameter table, the polyline's station pointers - is loop-invariant, and the compiler otherwise computes it
+  // ahead of the time loop and keeps it in registers the Newton loop does not have: they went to scratch, and the hinted path
+  // fetched its own table pointer and interval from scratch ahead of every evaluation, a memory round trip in front of the one it needs.)
+  __device__ __forceinline__ static int opaque(int node) { asm volatile("" : "+v"(node)); return node; }
   __device__ __forceinline__ NodeTerms<R> terms_hinted(int node, R h, R Q, int &kh, PolyBC<R> &bc) const {
-    if (kh == -2) return node_terms_general_call(section(node), h, Q);
-    return node_terms_poly_hinted(ptz + (size_t)node * poly_table_stride(pK), poly_table_bp(pK), tb.has_over, tb.n_over, kh, h, Q, bc,
-                                  [&]() { return terms_scan(*this, node, h, Q); });
+    if (kh == -2) return node_terms_general_call(section(opaque(node)), h, Q);
+    return node_terms_poly_hinted(table_slot(node), tb.N, tb.has_over, tb.n_over, kh, h, Q, bc,
+                                  [&]() { return terms_scan(*this, opaque(node), h, Q); });
   }
   // the same out of line: the kernels with many rows per lane evaluate 2 (M + 1) nodes per iteration - inlined, the polyline
   // code made them ~30 000 instructions long (and the 4-wave one of them miscompiled); two rows per lane keep it inline (+37 %)
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       polybc[j].K = R(0); polybc[j].dKdA = R(0); polybc[j].dAdh = R(0);
     }
   }
-  auto terms_at = [&](int j, R hh, R QQ) {
+  auto terms_at = [&](int j, R hh, R QQ) __attribute__((always_inline)) {
     if constexpr (kRegGeo) return node_terms_general(secs[j], hh, QQ);
     else if constexpr (kHinted) return geo.terms_hinted(min(s0 + j, N - 1), hh, QQ, khint[j], polybc[j]);
     else if constexpr (SEC == FS_SEC_IRREGULAR && M > 2) return geo.terms_call(min(s0 + j, N - 1), hh, QQ);
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   // whole section evaluation per iteration, executed by 64 lanes for a result nobody read: a quarter of the polyline ensemble's
   // instructions.)
   constexpr bool kShareNode = FS_SHARE_NODE && W == 1 && !Geo::kConstT;
-  auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) {
+  auto last_node_terms = [&](const NodeTerms<R> &first, R hM, R QM) __attribute__((always_inline)) {
     auto rol = [](R v) { return dpp_mov<0x134>(v); };     // wave_rol:1
     NodeTerms<R> r;
     r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eAT = rol(first.eAT); r.eQ = rol(first.eQ); r.v = rol(first.v);
@@ -540,7 +548,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     (void)hM; (void)QM;
     return r;
   };
-  auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+  auto write_level_constants = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) __attribute__((always_inline)) {
     NodeTerms<R> L = terms_at(0, hh[0], QQ[0]);
     NodeTerms<R> Rlast;
     if (kShareNode) Rlast = last_node_terms(L, hh[M], QQ[M]);
@@ -559,10 +567,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #endif
     }
   };
-  auto save_terms = [&](int j, const NodeTerms<R> &nt) {
+  auto save_terms = [&](int j, const NodeTerms<R> &nt) __attribute__((always_inline)) {
     if constexpr (kSaveTerms) { sm.nt[0][j][t] = nt.A; sm.nt[1][j][t] = nt.Se; sm.nt[2][j][t] = nt.v; }
   };
-  auto level_constants_from_saved = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+  auto level_constants_from_saved = [&](const R(&hh)[M + 1], const R(&QQ)[M + 1]) __attribute__((always_inline)) {
     if constexpr (kSaveTerms) {
       R A0 = sm.nt[0][0][t], Se0 = sm.nt[1][0][t], v0 = sm.nt[2][0][t];
 #pragma unroll
@@ -850,7 +858,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       __builtin_amdgcn_sched_barrier(0);   // phases are not interleaved: it only costs registers (measured around the down-sweep: +5 %)
 #endif
       // ================= 3. in-wave tree (up-sweep) =================
-      auto up_level = [&](auto lc) {
+      auto up_level = [&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         constexpr int d = 1 << l;
         const Seg<R> left = seg_from_below<d>(seg);
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         // Records stay in registers (valid in the lane that survives its level: low l + 1 bits set); on the way down the
         // group's record comes from the group's last lane by a quad permute (groups of 2 and 4 lanes) or a readlane (8).
         Elim<R> xe[LW];
-        auto xup = [&](auto lc) {
+        auto xup = [&](auto lc) __attribute__((always_inline)) {
           constexpr int l = decltype(lc)::value;
           constexpr int d = 1 << l;
           if constexpr (l < LW) {
@@ -919,7 +927,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         R p0, m0, ml;
         close_root(xs, sm.xbc[parity][0], sm.xbc[parity][1], sm.xbc[parity][2], p0, m0, ml);     // valid in lane W - 1
         R px = read_lane(p0, W - 1), mx = read_lane(ml, W - 1);
-        auto xdown = [&](auto lc) {
+        auto xdown = [&](auto lc) __attribute__((always_inline)) {
           constexpr int l = decltype(lc)::value;
           if constexpr (l < LW) {
             Elim<R> e;
@@ -1019,7 +1027,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       // group's first row and the m of its last one.  The group's record is one LDS slot that all its lanes read (a
       // broadcast read); each lane recovers the separator itself and keeps it as its new right number (lower half) or
       // turns it into its new left one (upper half): no cross-lane traffic, two dependent fp64 operations per level.
-      auto load_rec = [&](auto lc) {
+      auto load_rec = [&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         Elim<R> e;
         const int slot = (64 - (64 >> l)) + (ln >> (l + 1));
@@ -1027,7 +1035,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         e.A1 = p[0 * 64]; e.A2 = p[1 * 64]; e.A3 = p[2 * 64]; e.rc = p[3 * 64];
         return e;
       };
-      auto down_level = [&](auto lc, const Elim<R> &e) {
+      auto down_level = [&](auto lc, const Elim<R> &e) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         const R sep = separator(e, pL, mR);
         const bool upper = ((lane >> l) & 1) != 0;
@@ -1081,7 +1089,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         const R i2tc = dt * geo.rT_const();
         auto i2t_of = [&](int j) { return Geo::kConstT ? i2tc : iTn[j]; };
         // rc of row j for the link p_{j+1} = rc_j - m_j: minus the continuity residual of cell j, 0 beyond the cells
-        auto rc_of = [&](int j) {
+        auto rc_of = [&](int j) __attribute__((always_inline)) {
           if (Geo::kConstT) {
             const R v = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
             return (RAGGED && s0 + j >= NC) ? R(0) : v;

@@ -90,20 +90,20 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
   if (warn) status = FS_OK;
   if (t == 0) { sm.xflag = 0; sm.xwarn = 0; }
 
-  auto node_terms = [&](int node, R hh, R QQ) {
+  auto node_terms = [&](int node, R hh, R QQ) __attribute__((always_inline)) {
     if constexpr (SEC == FS_SEC_IRREGULAR) return geo.terms_call(node, hh, QQ);        // (out of line: see Geometry<R, FS_SEC_IRREGULAR>)
     else return geo.terms(node, hh, QQ);
   };
   // nodes g0 .. g0 + M of a pass's lane (clamped copies beyond the last node)
-  auto load_nodes = [&](const R *hs, const R *Qs, int g0, R(&h)[M + 1], R(&Q)[M + 1]) {
+  auto load_nodes = [&](const R *hs, const R *Qs, int g0, R(&h)[M + 1], R(&Q)[M + 1]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j <= M; ++j) {
       const int node = min(g0 + j, N - 1);
       h[j] = hs[base + node]; Q[j] = Qs[base + node];
     }
   };
-  auto kc_at = [&](int i, int p, int c) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
-  auto write_level_constants = [&](int p, int g0, const R(&hh)[M + 1], const R(&QQ)[M + 1]) {
+  auto kc_at = [&](int i, int p, int c) __attribute__((always_inline)) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
+  auto write_level_constants = [&](int p, int g0, const R(&hh)[M + 1], const R(&QQ)[M + 1]) __attribute__((always_inline)) {
     NodeTerms<R> L = node_terms(min(g0, N - 1), hh[0], QQ[0]);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
           int gi = hi_abs(seg.u3);
 
           // ---- in-wave tree, up ----
-          auto up_level = [&](auto lc) {
+          auto up_level = [&](auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
             constexpr int d = 1 << l;
             const Seg<R> left = seg_from_below<d>(seg);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
           const R *xr = sm.xres[p * W + wave];
           R pL = xr[0], mR = xr[1];
-          auto down_level = [&](auto lc) {
+          auto down_level = [&](auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
             const R *q = &sm.tree[wave][0][(64 - (64 >> l)) + (lane >> (l + 1))];
             Elim<R> e;
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
           if (lane == 63) mB = xr[3];
           R dh[M + 1], dQ[M + 1];
           {
-            auto rc_of = [&](int j) { return j + 1 < M ? el[j].qc.get() : rcLast; };
+            auto rc_of = [&](int j) __attribute__((always_inline)) { return j + 1 < M ? el[j].qc.get() : rcLast; };
             R mj = mR;
             {
               const R pM = rcLast - mR;
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
             int gx = sm.xg[sl];
             if (lane >= S) { xs.u1 = R(0); xs.u3 = R(0); xs.ru = R(0); xs.d1 = R(0); xs.d2 = R(1); xs.d3 = R(0); xs.rd = R(0); xs.rc = R(0); gx = 0; }
             const R u1o = xs.u1, u3o = xs.u3, ruo = xs.ru;
-            auto xup = [&](auto lc) {
+            auto xup = [&](auto lc) __attribute__((always_inline)) {
               constexpr int l = decltype(lc)::value;
               constexpr int d = 1 << l;
               const Seg<R> left = seg_from_below<d>(xs);
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
             R p0, m0, ml;
             close_root(xs, sm.xbc[0], sm.xbc[1], sm.xbc[2], p0, m0, ml);        // valid in lane 63
             R px = read_lane(p0, 63), mx = read_lane(ml, 63);
-            auto xdown = [&](auto lc) {
+            auto xdown = [&](auto lc) __attribute__((always_inline)) {
               constexpr int l = decltype(lc)::value;
               const R *w = &sm.xtree[0][(64 - (64 >> l)) + (lane >> (l + 1))];
               Elim<R> e;

@@ -39,13 +39,17 @@ template <typename R> struct PolyNode {
   const R *x, *z;
   int stride, n;
   R nl, nm, nr, liml, limr, curv, zmin;
-  // stage table of the node (fs_abi.hip: build_stage_table), one contiguous 16-byte aligned block per node - a lane fetches its
-  // own breakpoints and the coefficients of its own interval with 16-byte loads from two or three cache lines (a first,
-  // vertex-major layout took one 8-byte gather per number: 40 load instructions per node evaluation, each touching up to 64
-  // cache lines - the kernel then waited on the texture path for 63 % of its cycles).  tz == nullptr: no table, walk the edges.
-  const R *tz;             // [KP] breakpoints: the distinct vertex elevations, ascending, padded with +inf (KP even), followed by
-                           // [K][FS_PT_BLOCK] per interval k = (tz[k], tz[k + 1]]: FS_PT_NCOEF coefficients in u = stage - tz[k], then
-                           // the number of wetted runs of >= 2 vertices (get_subchannels, cross_section.py:330-370) as a double
+  // Stage table (fs_abi.hip: build_stage_table; tz == nullptr: none, walk the edges).  Two parts per channel:
+  //   breakpoints  [N][KP]: the node's distinct vertex elevations, ascending, padded with +inf (KP a multiple of 16);
+  //   intervals    [K][FS_PT_BLOCK / 2][N] 16-byte pairs: for interval k = (z_k, z_k+1] of a node FS_PT_NCOEF coefficients in
+  //                u = stage - z_k, then what FS_PT_* lists.  NODE-MINOR: the lanes of a wave sit on consecutive nodes, and
+  //                neighbouring nodes are wetted to the same interval nearly everywhere, so one load instruction of the
+  //                wave touches a few cache lines.  (A first layout kept each node's intervals in one 256-byte block: a
+  //                single fetch per lane, but every one of its 16 load instructions then touched 64 different lines - the
+  //                texture addresser takes a cycle per line, TA_TA_BUSY 78 % of the kernel, profiles/round3.)
+  const R *tz;             // the node's breakpoints
+  const R *tco;            // the node's slot in the interval part (pair 0 of interval 0); cstride pairs from pair to pair
+  int cstride;
   int K, KP;
 };
 
@@ -65,7 +69,7 @@ enum { FS_PT_A0 = 0, FS_PT_A1, FS_PT_A2, FS_PT_P0, FS_PT_P1, FS_PT_T0, FS_PT_T1,
 // doubles of one node's stage table for polylines of up to P vertices
 // (the breakpoints padded with +inf to a multiple of 16: the scan fetches them 16 at a time, eight 16-byte loads in flight)
 __host__ __device__ constexpr int poly_table_bp(int P) { return (P + 16) & ~15; }
-__host__ __device__ constexpr int poly_table_stride(int P) { return poly_table_bp(P) + P * FS_PT_BLOCK; }
+__host__ __device__ constexpr int poly_table_stride(int P) { return poly_table_bp(P) + P * FS_PT_BLOCK; }   // per node, both parts
 
 // vertices [lo, hi] of a node, optionally extended by a water's-edge point at elevation zc on
 // either side (the x_seg / z_seg of cross_section.py:352-365)
@@ -227,14 +231,14 @@ __device__ __forceinline__ PolySums<R> poly_sums_table(const R (&co)[FS_PT_USED]
   return q;
 }
 
-// the block of interval k of a node's stage table (tz: the node's table, KP breakpoints ahead of the blocks)
+// interval k of a node's stage table (tco: the node's slot in the interval part, cstride: 16-byte pairs between two pairs of it)
 template <typename R>
-__device__ __forceinline__ void poly_load_block(const R *tz, int KP, int k, R (&co)[FS_PT_USED]) {
+__device__ __forceinline__ void poly_load_block(const R *tco, int cstride, int k, R (&co)[FS_PT_USED]) {
   typedef R R2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) R2 *GlobalR2;
-  const GlobalR2 cb = (GlobalR2)(tz + KP + (size_t)k * FS_PT_BLOCK);
+  const GlobalR2 cb = (GlobalR2)tco + (size_t)k * (FS_PT_BLOCK / 2) * cstride;
 #pragma unroll
-  for (int i = 0; i < FS_PT_USED / 2; ++i) { const R2 v = cb[i]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
+  for (int i = 0; i < FS_PT_USED / 2; ++i) { const R2 v = cb[(size_t)i * cstride]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
 }
 
 // *kout (optional): the interval the stage was found in, -1 when the evaluation went back to the edge walk
@@ -268,7 +272,7 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, 
   *nsub = 0;
   if (c1 > 0) {
     R co[FS_PT_USED];
-    poly_load_block(nd.tz, nd.KP, c1 - 1, co);
+    poly_load_block(nd.tco, nd.cstride, c1 - 1, co);
     q = poly_sums_table(co, co[FS_PT_ZLO], hw);
     *nsub = (int)co[FS_PT_NSUB];
     if (kout) *kout = c1 - 1;
@@ -352,7 +356,7 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
 
 // The same from the interval of the node's last evaluation.  A Newton iterate moves the stage by far less than the distance
 // between two vertex elevations, so nearly every evaluation finds its stage in the interval the last one used: ONE fetch of
-// that interval's block (it brings the interval's bounds and the node's constants with it, see FS_PT_*), no breakpoint scan, no
+// that interval's entry (it brings the interval's bounds and the node's constants with it, see FS_PT_*), no breakpoint scan, no
 // per-node parameter loads - one memory round trip where the scan path has three in a row (node parameters, breakpoints,
 // coefficients).  Same coefficients, same arithmetic: the result is bitwise that of node_terms_poly.  `slow` is called (with
 // nothing fetched) when there is no interval to start from, when the stage has left it, or when the interval has two or more
@@ -360,11 +364,11 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
 template <typename R> struct TermsHint { NodeTerms<R> t; PolyBC<R> bc; int k; };
 
 template <typename R, typename Slow>
-__device__ __forceinline__ NodeTerms<R> node_terms_poly_hinted(const R *tz, int KP, bool has_over, R n_over, int &kh, R h, R Q,
+__device__ __forceinline__ NodeTerms<R> node_terms_poly_hinted(const R *tco, int cstride, bool has_over, R n_over, int &kh, R h, R Q,
                                                                PolyBC<R> &bc, Slow slow) {
   if (kh >= 0) {
     R co[FS_PT_USED];
-    poly_load_block(tz, KP, kh, co);
+    poly_load_block(tco, cstride, kh, co);
     const R hw = h + co[FS_PT_ZMIN], dh = R(1e-6);
     if (co[FS_PT_ZLO] < hw - dh && co[FS_PT_ZHI] > hw + dh && co[FS_PT_NSUB] < R(2)) {
       PolyNode<R> nd;                                      // (poly_finish reads the three Manning values only)
