@@ -97,6 +97,8 @@ const Entry kEntries[] = {FS_ENTRY_X(float, FS_F32, FS_SEC_TRAP_UNIFORM, 8, 1, 1
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, false)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 2, 1, false)
                           FS_ENTRY_X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 2, 4, 1, false)};
+#elif defined(FS_MINIMAL) && FS_MINIMAL == 3   // experiment builds: the polyline kernels
+const Entry kEntries[] = {FS_LIST_IRREGULAR(FS_TABLE_ROW)};
 #elif defined(FS_MINIMAL)   // experiment builds: just the flagship shapes
 const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, FS_BCK(FS_BC_NORMAL_DEPTH))

@@ -537,7 +537,7 @@ __device__ R storage_root(const StorageCurve<R> &sc, R Yold, R vol_in, R dt, R s
 // fixed_depth + general LumpedStorage: residual and derivatives of boundary.py:97-133, :152-164, :213-237.
 // pr: section at hw = z_min + depth (residual), pd: at hw = depth + bed_level (derivatives).
 template <typename R>
-__device__ __noinline__ BCRow<R> bc_storage_curve(const BCDesc<R> bc, int reach, int B, int level, const EntryProps<R> pr,
+__device__ __forceinline__ BCRow<R> bc_storage_curve(const BCDesc<R> bc, int reach, int B, int level, const EntryProps<R> pr,
                                                   const EntryProps<R> pd, R h, R Q, R Qold, R dt, R Yprev, R *Ynew,
                                                   int *flag) {
   StorageCurve<R> sc{bc, reach, B, 0};

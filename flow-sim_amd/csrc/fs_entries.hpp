@@ -94,6 +94,7 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
 #define FS_LIST_IRREGULAR(X) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, 0) \
+  X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, -1) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 4, 0, -1)

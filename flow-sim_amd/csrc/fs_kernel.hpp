@@ -49,9 +49,6 @@
 #ifndef FS_POLY_HINT
 #define FS_POLY_HINT 1     // polyline nodes start from the stage-table interval of their last evaluation (fs_poly.hpp)
 #endif
-#ifndef FS_POLY_SLOW_INLINE
-#define FS_POLY_SLOW_INLINE 1   // the scan / edge-walk path behind the hinted evaluation inline too (out of line: -6 % on the polyline ensemble, the call pins registers)
-#endif
 #ifndef FS_SHARE_NODE
 #define FS_SHARE_NODE 1    // one-wave-per-reach kernels with general sections: a lane's last node is its right neighbour's first -
 #endif                     // take the neighbour's node terms (12 DPP moves) instead of evaluating the node a second time
@@ -364,12 +361,7 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   __device__ __forceinline__ int hint_init(int node) const {
     return ((const __attribute__((address_space(1))) int32_t *)pn)[node] > 0 ? -1 : -2;
   }
-#if FS_POLY_SLOW_INLINE
-  __device__ __forceinline__
-#else
-  __device__ __noinline__
-#endif
-  static TermsHint<R> terms_scan(const Geometry g, int node, R h, R Q) {
+  __device__ __forceinline__ static TermsHint<R> terms_scan(const Geometry g, int node, R h, R Q) {
     TermsHint<R> r;
     r.t = node_terms_poly(g.poly(node), h, Q, &r.k, &r.bc);
     return r;
@@ -384,9 +376,12 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
     return node_terms_poly_hinted(table_slot(node), tb.N, tb.has_over, tb.n_over, kh, h, Q, bc,
                                   [&]() { return terms_scan(*this, opaque(node), h, Q); });
   }
-  // the same out of line: the kernels with many rows per lane evaluate 2 (M + 1) nodes per iteration - inlined, the polyline
-  // code made them ~30 000 instructions long (and the 4-wave one of them miscompiled); two rows per lane keep it inline (+37 %)
-  __device__ __noinline__ NodeTerms<R> terms_call(int node, R h, R Q) const { return terms(node, h, Q); }
+  // (No device function of this library is called out of line.  Until round 3 the kernels with many rows per lane called the
+  // polyline evaluation, and the edge walk behind the stage tables was a call everywhere: the compiler's interprocedural register
+  // allocation then trusted a register summary of the callee that did not hold - the (8, 1) polyline kernel returned wrong numbers
+  // from the second level on, or not, depending on unrelated code around the call, the (8, 4) one faulted, and both are correct
+  // with -mllvm -enable-ipra=0.  Inlined, nothing is left to summarise; the kernels are also faster: (2, 1) +8 %, (8, 1) +16 %,
+  // (8, 4) +32 % on the polyline ensemble, profiles/round3/polyline_calls.txt.)
   template <int BCK, int SIDE>
   __device__ __forceinline__ BCRow<R> boundary(const BCDesc<R> &bc_, int reach, int B, int level, int node, R h, R Q,
                                                R Qold, R dt, R Yprev, R *Ynew, int *flag) const {
@@ -499,7 +494,6 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   auto terms_at = [&](int j, R hh, R QQ) __attribute__((always_inline)) {
     if constexpr (kRegGeo) return node_terms_general(secs[j], hh, QQ);
     else if constexpr (kHinted) return geo.terms_hinted(min(s0 + j, N - 1), hh, QQ, khint[j], polybc[j]);
-    else if constexpr (SEC == FS_SEC_IRREGULAR && M > 2) return geo.terms_call(min(s0 + j, N - 1), hh, QQ);
     else return geo.terms(min(s0 + j, N - 1), hh, QQ);
   };
 
@@ -541,10 +535,6 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     NodeTerms<R> r;
     r.A = rol(first.A); r.T = rol(first.T); r.Se = rol(first.Se); r.eAT = rol(first.eAT); r.eQ = rol(first.eQ); r.v = rol(first.v);
     r.rT = rol(first.rT);
-    // (kept for the kernels with more than two rows per lane, where it is one evaluation in M + 1: the (8, 1) polyline kernel
-    // compiled without it fails its fixture although a 13-node reach never takes this branch - like its (8, 4) sibling, see
-    // fs_entries.hpp; unexplained, so the working code stays)
-    if constexpr (M > 2) { if (NC >= 64 * M - 1 && lane == 63) r = terms_at(M, hM, QM); }
     (void)hM; (void)QM;
     return r;
   };

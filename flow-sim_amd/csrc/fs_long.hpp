@@ -91,8 +91,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
   if (t == 0) { sm.xflag = 0; sm.xwarn = 0; }
 
   auto node_terms = [&](int node, R hh, R QQ) __attribute__((always_inline)) {
-    if constexpr (SEC == FS_SEC_IRREGULAR) return geo.terms_call(node, hh, QQ);        // (out of line: see Geometry<R, FS_SEC_IRREGULAR>)
-    else return geo.terms(node, hh, QQ);
+    return geo.terms(node, hh, QQ);
   };
   // nodes g0 .. g0 + M of a pass's lane (clamped copies beyond the last node)
   auto load_nodes = [&](const R *hs, const R *Qs, int g0, R(&h)[M + 1], R(&Q)[M + 1]) __attribute__((always_inline)) {

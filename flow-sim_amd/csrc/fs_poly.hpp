@@ -206,7 +206,7 @@ template <typename R> __device__ __forceinline__ PolyView<R> poly_whole(const Po
 // made the 4-wave polyline kernel 30 000 instructions long, and that kernel then died at launch (long-branch expansion with no
 // scalar register to spare); the sub-section walks of a split section stay inline, as before.
 template <typename R>
-__device__ __noinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R hw) {
+__device__ __forceinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R hw) {
   return poly_finish(nd, poly_sums_walk(nd, poly_whole(nd), hw));
 }
 
