@@ -315,6 +315,9 @@ struct fs_batch {
   void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
   int32_t *iters = nullptr, *status = nullptr;
   int32_t *it_done = nullptr;          // [B] Newton iterations spent on the open level (fs_batch_iterate)
+  double *ends_dev = nullptr;          // [4][B] scratch of fs_batch_get_boundary_iterate (allocated on first use)
+  double *ends_pin = nullptr;          // its pinned host mirror
+  int32_t *open_dev = nullptr, *open_pin = nullptr;      // fs_batch_iterate: count of the reaches still iterating
   void *derived[8] = {nullptr};        // device results of the last derive call, kept and reused
   size_t derived_cap[8] = {0};         // their capacities in elements
   unsigned long long *dbg = nullptr;
@@ -419,6 +422,24 @@ std::vector<double> extend_table(const double *t, size_t N) {
     put(fs::FS_GEOX_KL15, nl > 0 ? std::pow(nl, -1.5) : 0.0); put(fs::FS_GEOX_KR15, nr > 0 ? std::pow(nr, -1.5) : 0.0);
   }
   return x;
+}
+
+// the Newton vector at the two ends of every reach, as doubles: out[4][B] = h_0, Q_0, h_last, Q_last (fs_batch_get_boundary_iterate)
+template <typename R>
+__global__ void gather_boundary_iterate(const R *hg, const R *Qg, const int32_t *reach_nodes, double *out, size_t B, size_t N) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const size_t last = (reach_nodes ? (size_t)reach_nodes[r] : N) - 1;
+  out[r] = (double)hg[r * N]; out[B + r] = (double)Qg[r * N];
+  out[2 * B + r] = (double)hg[r * N + last]; out[3 * B + r] = (double)Qg[r * N + last];
+}
+
+// reaches whose open level still iterates (fs_batch_iterate): not yet accepted and not failed
+__global__ void count_open_reaches(const int32_t *done, const int32_t *status, int32_t *out, size_t B) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool open = r < B && done[r] >= 0 && (status[r] == FS_OK || status[r] == FS_ILL_CONDITIONED);   // (a warning, not a failure)
+  const unsigned long long m = __ballot(open);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int32_t)__popcll(m));
 }
 
 // level 0 of every array from one (h, Q) pair per reach
@@ -590,8 +611,10 @@ void fs_batch_destroy(fs_batch *b) {
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
-                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz};
+                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->ends_dev, b->open_dev};
   for (void *p : bufs) if (p) (void)hipFree(p);
+  if (b->ends_pin) (void)hipHostFree(b->ends_pin);
+  if (b->open_pin) (void)hipHostFree(b->open_pin);
   for (void *p : b->derived) if (p) (void)hipFree(p);
   b->stage.release();
   if (b->ev0) (void)hipEventDestroy(b->ev0);
@@ -903,6 +926,11 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
       HIP_TRY(hipMemsetAsync(b->bc_params[side], 0, 3 * B * b->esz, b->stream));
     }
     b->bc_kind[side] = kind; b->bc_stride[side] = 1; b->have_bc[side] = true;
+    b->kinds_per_reach[side] = false;
+    if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
+      std::vector<int32_t> same(B, kind);
+      HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
+    }
     return 0;
   }
   if (kind == FS_BC_STORAGE_CURVE) {
@@ -1018,13 +1046,18 @@ int fs_batch_iterate(fs_batch *b, int32_t *n_open) {
   FS_ON_DEVICE(b);
   if (launch_steps(b, 1, 1)) return -1;
   b->iterating = true;
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  // how many reaches are still open: counted on the device, four bytes come back (until round 3: two B-sized downloads per iteration)
   const size_t B = b->d.n_reaches;
-  std::vector<int32_t> done(B), st(B);
-  HIP_TRY(hipMemcpy(done.data(), b->it_done, B * 4, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(st.data(), b->status, B * 4, hipMemcpyDeviceToHost));
-  int32_t open = 0;
-  for (size_t r = 0; r < B; ++r) open += (done[r] >= 0 && (st[r] == FS_OK || st[r] == FS_ILL_CONDITIONED)) ? 1 : 0;   // (a warning, not a failure)
+  if (!b->open_dev) {
+    HIP_TRY(hipMalloc((void **)&b->open_dev, sizeof(int32_t)));
+    HIP_TRY(hipHostMalloc((void **)&b->open_pin, sizeof(int32_t), hipHostMallocDefault));
+  }
+  HIP_TRY(hipMemsetAsync(b->open_dev, 0, sizeof(int32_t), b->stream));
+  hipLaunchKernelGGL(count_open_reaches, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, b->stream, b->it_done, b->status, b->open_dev, B);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(b->open_pin, b->open_dev, sizeof(int32_t), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const int32_t open = *b->open_pin;
   if (open == 0) {      // every reach has accepted the level (or failed on it): next level, counters back to zero
     b->level += 1;
     b->iterating = false;
@@ -1047,13 +1080,24 @@ int fs_batch_get_boundary_iterate(fs_batch *b, double *out) {
   if (!b || !out) return fail("fs_batch_get_boundary_iterate: null argument");
   if (!b->have_state) return fail("fs_batch_get_boundary_iterate: no state yet");
   FS_ON_DEVICE(b);
+  // one gather kernel and one transfer through a pinned buffer per call (it is made once per Newton iteration): until round 3 this
+  // was four strided hipMemcpy2D of one element per reach
+  const size_t B = b->d.n_reaches, N = b->d.n_nodes;
+  if (!b->ends_dev) {
+    HIP_TRY(hipMalloc((void **)&b->ends_dev, 4 * B * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&b->ends_pin, 4 * B * sizeof(double), hipHostMallocDefault));
+  }
+  const dim3 grid((unsigned)((B + 255) / 256));
+  if (b->d.dtype == FS_F64)
+    hipLaunchKernelGGL((gather_boundary_iterate<double>), grid, dim3(256), 0, b->stream, (const double *)b->hg, (const double *)b->Qg,
+                       b->reach_nodes, b->ends_dev, B, N);
+  else
+    hipLaunchKernelGGL((gather_boundary_iterate<float>), grid, dim3(256), 0, b->stream, (const float *)b->hg, (const float *)b->Qg,
+                       b->reach_nodes, b->ends_dev, B, N);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(b->ends_pin, b->ends_dev, 4 * B * sizeof(double), hipMemcpyDeviceToHost, b->stream));
   HIP_TRY(hipStreamSynchronize(b->stream));
-  const size_t B = b->d.n_reaches, N = b->d.n_nodes, e = b->esz;
-  std::vector<char> tmp(4 * B * e);
-  const void *src[4] = {b->hg, b->Qg, (const char *)b->hg + (N - 1) * e, (const char *)b->Qg + (N - 1) * e};
-  for (int i = 0; i < 4; ++i)      // one element per reach: a strided copy (rows of N elements, one column)
-    HIP_TRY(hipMemcpy2D(tmp.data() + (size_t)i * B * e, e, src[i], N * e, e, B, hipMemcpyDeviceToHost));
-  for (size_t i = 0; i < 4 * B; ++i) out[i] = e == 8 ? ((const double *)tmp.data())[i] : (double)((const float *)tmp.data())[i];
+  std::memcpy(out, b->ends_pin, 4 * B * sizeof(double));
   return 0;
 }
 

@@ -258,7 +258,8 @@ template <typename R> struct GeneralProps { R A, rA, P, Rh, T, rT, K, rK, neq, d
 // pow()-heavy and only the boundary rows and the TABLE geometry mode use it.
 // general boundary rows (bc_eval) in line or out of line
 #ifndef FS_BC_INLINE
-#define FS_BC_INLINE 1   // measured on the one-wave-per-reach kernels: C4 +8 %, C5 +4 % (fp64) / +15 % (fp32); a call inside the Newton loop spills the caller around it
+#define FS_BC_INLINE 1   // (0, like FS_GENERAL_INLINE 0: experiment switches, to be built with -mllvm -enable-ipra=0, profiles/round3/polyline_calls.txt)
+                         // measured on the one-wave-per-reach kernels: C4 +8 %, C5 +4 % (fp64) / +15 % (fp32); a call inside the Newton loop spills the caller around it
 #endif
 #if FS_BC_INLINE
 #define FS_BC_ATTR __forceinline__

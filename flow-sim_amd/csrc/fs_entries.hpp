@@ -88,9 +88,7 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
   X(R, DT, FS_SEC_TABLE, 8, 2, 0, -1) \
   X(R, DT, FS_SEC_TABLE, 8, 4, 0, -1)
 
-// polyline sections: fp64 only, a few shapes (the section evaluation dominates, not the elimination).  No (8, 4) kernel of class 0:
-// with the stage-table code that instantiation (256 + 256 registers, every scalar register, 36 spills) faulted on its first
-// launch while its class -1 sibling - a superset - is fine; reaches of 513 ... 2 048 polyline nodes run on that one.
+// polyline sections: fp64 only, a few shapes (the section evaluation dominates, not the elimination)
 #define FS_LIST_IRREGULAR(X) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 8, 1, 0, 0) \

@@ -20,6 +20,7 @@
 
 #ifndef FS_POLY_INLINE
 #define FS_POLY_INLINE 1   // polyline walk inlined into the fold (+37 % on the polyline ensemble): a call inside the Newton loop spills its caller
+                           // (0 is an experiment switch: build it with -mllvm -enable-ipra=0, profiles/round3/polyline_calls.txt)
 #endif
 #if FS_POLY_INLINE
 #define FS_POLY_ATTR __forceinline__
@@ -201,10 +202,9 @@ template <typename R> __device__ __forceinline__ PolyView<R> poly_whole(const Po
 // ~25 coefficient loads and as many fmas stand in for the walk over all edges.  *nsub returns the number of wetted runs of
 // >= 2 vertices (1 when there is no table: the caller then counts them itself).  A stage that coincides with a vertex
 // elevation to the last bit goes back to the edge walk (there the reference drops the two edges at that vertex, :262).
-// The edge walk over the whole section, out of line: with stage tables it only runs when a stage hits a vertex elevation to the
-// last bit (or when the tables are switched off, FS_POLY_WALK=1).  Inlined at every node evaluation next to the table path it
-// made the 4-wave polyline kernel 30 000 instructions long, and that kernel then died at launch (long-branch expansion with no
-// scalar register to spare); the sub-section walks of a split section stay inline, as before.
+// The edge walk over the whole section: with stage tables it only runs when a stage hits a vertex elevation to within 1e-6 (or
+// when the tables are switched off, FS_POLY_WALK=1).  Inline like everything else (fs_kernel.hpp, Geometry<R, FS_SEC_IRREGULAR>: a
+// call here was what the compiler's interprocedural register allocation tripped over).
 template <typename R>
 __device__ __forceinline__ PolyEval<R> poly_eval_whole_walk(const PolyNode<R> nd, R hw) {
   return poly_finish(nd, poly_sums_walk(nd, poly_whole(nd), hw));
