@@ -46,6 +46,9 @@
 #ifndef FS_SAVE_TERMS
 #define FS_SAVE_TERMS 1
 #endif
+#ifndef FS_POLY_HINT_MAXM
+#define FS_POLY_HINT_MAXM 8
+#endif
 #ifndef FS_POLY_HINT
 #define FS_POLY_HINT 1     // polyline nodes start from the stage-table interval of their last evaluation (fs_poly.hpp)
 #endif
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     for (int j = 0; j <= M; ++j) secs[j] = geo.section(min(s0 + j, N - 1));
   }
   // polyline nodes: the stage-table interval each of the lane's nodes was last evaluated in (Geometry::terms_hinted)
-  constexpr bool kHinted = SEC == FS_SEC_IRREGULAR && M <= 2 && FS_POLY_HINT;
+  constexpr bool kHinted = SEC == FS_SEC_IRREGULAR && M <= FS_POLY_HINT_MAXM && FS_POLY_HINT;
   int khint[kHinted ? M + 1 : 1];
   PolyBC<R> polybc[kHinted ? M + 1 : 1];      // (K, dK/dA, dA/dh) of the lane's nodes as last evaluated: the fused normal-depth row below
   if constexpr (kHinted) {
