@@ -494,7 +494,9 @@ int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
   if (k->longk) {      // a reach longer than one lane grid: passes of 64 W M rows, level constants in a scratch of the batch's own
     const size_t chunk = (size_t)64 * k->W * k->M;
     b->passes = (int)((b->d.n_nodes + chunk - 1) / chunk);
-    const size_t need = (size_t)b->d.n_reaches * 4 * b->passes * chunk;
+    // (uniform sections recompute their level constants, fs_long.hpp: no scratch)
+    const bool recompute = FS_LONG_RECOMPUTE && (b->d.section_mode == FS_SEC_RECT_UNIFORM || b->d.section_mode == FS_SEC_TRAP_UNIFORM);
+    const size_t need = recompute ? 0 : (size_t)b->d.n_reaches * 4 * b->passes * chunk;
     if (b->kc_scratch_elems < need) {
       if (b->kc_scratch) { (void)hipFree(b->kc_scratch); b->kc_scratch = nullptr; b->kc_scratch_elems = 0; }
       HIP_TRY(hipMalloc(&b->kc_scratch, need * b->esz));

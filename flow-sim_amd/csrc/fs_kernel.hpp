@@ -46,6 +46,12 @@
 #ifndef FS_SAVE_TERMS
 #define FS_SAVE_TERMS 1
 #endif
+#ifndef FS_LONG_RECOMPUTE
+#define FS_LONG_RECOMPUTE 1   // multi-pass kernel, uniform sections: level constants recomputed per sweep instead of stored (fs_long.hpp)
+#endif
+#ifndef FS_LONG_WPE
+#define FS_LONG_WPE 2
+#endif
 #ifndef FS_POLY_HINT_MAXM
 #define FS_POLY_HINT_MAXM 8
 #endif

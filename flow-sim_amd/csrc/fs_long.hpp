@@ -40,11 +40,21 @@ template <typename R, int W> struct SmemLong {
   int32_t xflag, xwarn;
 };
 
+// waves per SIMD the kernel is compiled for: without the level constants in flight the uniform-section kernels need 298 registers;
+// capped at 256 two workgroups share a CU and one covers the other's memory waits (FS_LONG_WPE)
+template <typename R, int SEC> constexpr int long_min_waves() {
+  return (FS_LONG_RECOMPUTE && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM) && sizeof(R) == 8) ? FS_LONG_WPE : 1;
+}
+
 template <typename R, int SEC, int M, int W, int BCK>
-__global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const KernelArgs<R> a) {
+__global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann_long_kernel(const KernelArgs<R> a) {
   static_assert(BCK == 0 || BCK == -1, "long reaches: run-time boundary kinds only");
   constexpr int T = 64 * W, C = T * M;
   using Geo = Geometry<R, SEC>;
+  // Uniform sections: the four level constants of a cell are recomputed in every sweep from the accepted state of level k (two node
+  // evaluations of ~40 instructions) instead of being fetched from a scratch: 16 B instead of 32 B per node and sweep for a kernel
+  // that is bound by HBM.  Same expressions as the stored ones, hence the same bits.
+  constexpr bool kRecompute = FS_LONG_RECOMPUTE && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM);
   __shared__ SmemLong<R, W> sm;
 
   const int reach = blockIdx.x;
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
   const int N = a.reach_nodes ? a.reach_nodes[reach] : a.N, NC = N - 1;
   const int P = a.passes;                                     // P C >= N rows, P W <= 64 segments
   const size_t RP = (size_t)P * C;
-  R *const kcg = a.kc_scratch + (size_t)reach * 4 * RP;
+  R *const kcg = kRecompute ? nullptr : a.kc_scratch + (size_t)reach * 4 * RP;
   const size_t base = (size_t)reach * NS;
   // the row N-1 (downstream boundary row) and the node N-1: pass, lane, local index
   const int pD = NC / C, tD = (NC - pD * C) / M, jD = NC - pD * C - tD * M;
@@ -102,16 +112,22 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
     }
   };
   auto kc_at = [&](int i, int p, int c) __attribute__((always_inline)) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
+  // the four constants of cell (node, node + 1) from the node terms and unknowns of level k (one source for the stored and the recomputed ones)
+  auto level_constants = [&](const NodeTerms<R> &L, const NodeTerms<R> &Rn, R h0, R h1, R Q0, R Q1, int cell, R(&k)[4]) __attribute__((always_inline)) {
+    const R sumA = L.A + Rn.A;
+    k[0] = fma_(cqk, Q1 - Q0, -(sumA * r2dt));
+    k[1] = fma_(cqk, fma_(Q1, Rn.v, -(Q0 * L.v)), -((Q1 + Q0) * r2dt));
+    k[2] = ghthk * sumA;
+    k[3] = fma_(cqk, geo.bed_step(cell) + (h1 - h0), hthk * (L.Se + Rn.Se));
+  };
   auto write_level_constants = [&](int p, int g0, const R(&hh)[M + 1], const R(&QQ)[M + 1]) __attribute__((always_inline)) {
     NodeTerms<R> L = node_terms(min(g0, N - 1), hh[0], QQ[0]);
 #pragma unroll
     for (int c = 0; c < M; ++c) {
       const NodeTerms<R> Rn = node_terms(min(g0 + c + 1, N - 1), hh[c + 1], QQ[c + 1]);
-      const R sumA = L.A + Rn.A;
-      kc_at(0, p, c) = fma_(cqk, QQ[c + 1] - QQ[c], -(sumA * r2dt));
-      kc_at(1, p, c) = fma_(cqk, fma_(QQ[c + 1], Rn.v, -(QQ[c] * L.v)), -((QQ[c + 1] + QQ[c]) * r2dt));
-      kc_at(2, p, c) = ghthk * sumA;
-      kc_at(3, p, c) = fma_(cqk, geo.bed_step(g0 + c) + (hh[c + 1] - hh[c]), hthk * (L.Se + Rn.Se));
+      R k[4];
+      level_constants(L, Rn, hh[c], hh[c + 1], QQ[c], QQ[c + 1], g0 + c, k);
+      kc_at(0, p, c) = k[0]; kc_at(1, p, c) = k[1]; kc_at(2, p, c) = k[2]; kc_at(3, p, c) = k[3];
       L = Rn;
     }
   };
@@ -126,7 +142,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
 #pragma unroll
       for (int j = 0; j < M; ++j) if (j == jD) QoldD = Qk[j];
     }
-    write_level_constants(p, g0, hk, Qk);
+    if constexpr (!kRecompute) write_level_constants(p, g0, hk, Qk);
   }
   __syncthreads();
 
@@ -154,6 +170,8 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
           }
           R h[M + 1], Q[M + 1];
           load_nodes(a.hg, a.Qg, g0, h, Q);
+          R hk_[kRecompute ? M + 1 : 1], Qk_[kRecompute ? M + 1 : 1];     // accepted state of level k at the lane's nodes
+          if constexpr (kRecompute) load_nodes(a.hk, a.Qk, g0, hk_, Qk_);
           if (phase == 1) __syncthreads();          // every lane holds its nodes before any lane stores updated ones
 
           // ---- boundary rows (boundary.py:56-242) ----
@@ -190,9 +208,19 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
               sm.xbc[0] = x + y; sm.xbc[1] = x - y; sm.xbc[2] = -Urow.res;
             }
             R rcPrev = R(0);
+            NodeTerms<R> Lk;
+            if constexpr (kRecompute) Lk = node_terms(min(g0, N - 1), hk_[0], Qk_[0]);
 #pragma unroll
             for (int c = 0; c < M; ++c) {
-              const R k0 = kc_at(0, p, c), k1 = kc_at(1, p, c), k2 = kc_at(2, p, c), k3 = kc_at(3, p, c);
+              R kk[4];
+              if constexpr (kRecompute) {
+                const NodeTerms<R> Rk = node_terms(min(g0 + c + 1, N - 1), hk_[c + 1], Qk_[c + 1]);
+                level_constants(Lk, Rk, hk_[c], hk_[c + 1], Qk_[c], Qk_[c + 1], g0 + c, kk);
+                Lk = Rk;
+              } else {
+                kk[0] = kc_at(0, p, c); kk[1] = kc_at(1, p, c); kk[2] = kc_at(2, p, c); kk[3] = kc_at(3, p, c);
+              }
+              const R k0 = kk[0], k1 = kk[1], k2 = kk[2], k3 = kk[3];
               const NodeTerms<R> Rn = node_terms(min(g0 + c + 1, N - 1), h[c + 1], Q[c + 1]);
               const R i2tR = dt * Rn.rT;
               iTn[c + 1] = i2tR;
@@ -324,7 +352,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
 #pragma unroll
             for (int j = 0; j < M; ++j) {
               if (g0 + j < N) {
-                if (last) { a.hk[base + g0 + j] = h[j]; a.Qk[base + g0 + j] = Q[j]; }
+                if (last || kRecompute) { a.hk[base + g0 + j] = h[j]; a.Qk[base + g0 + j] = Q[j]; }
                 if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
               }
             }
@@ -339,7 +367,7 @@ __global__ __launch_bounds__(64 * W, 1) void preissmann_long_kernel(const Kernel
               Yprev = Ynew;
               if (ds_storage) a.stage_hist[(size_t)level * a.B + reach] = Ynew;
             }
-            write_level_constants(p, g0, h, Q);
+            if constexpr (!kRecompute) write_level_constants(p, g0, h, Q);
           }
 #pragma unroll
           for (int j = 0; j < M; ++j)
