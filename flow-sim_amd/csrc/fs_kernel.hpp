@@ -688,6 +688,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       ++it;
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
       parity ^= 1;
+      bool grow = false;                        // conditioning monitor: this iteration's segments grew past the limit
       FS_T(7);
 
       // opaque lane offset (an integer, so the accesses stay LDS ds_read, not flat): the 4*M level
@@ -951,7 +952,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         pL = read_lane(px, ws); mR = read_lane(mx, ws); mAw = read_lane(max_, ws);
         mBw = read_lane(max_, (ws + 1) & (W - 1));
         if (ws == W - 1) mBw = R(0);
-        if constexpr (kMonitor) { if (__builtin_amdgcn_readlane(gx, W - 1) > growth_limit_bits<R>()) warn = true; }
+        if constexpr (kMonitor) { if (__builtin_amdgcn_readlane(gx, W - 1) > growth_limit_bits<R>()) grow = true; }
       } else {
       {
         // pairwise tree over the W wave segments (depth log2 W instead of a serial chain of W-1 merges;
@@ -978,7 +979,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
             merge(sw[i], sw[i + st], sw[i], we[i + st - 1]);
             if constexpr (kMonitor) gx = max_(gx, hi_abs(sw[i].u3));
           }
-        if constexpr (kMonitor) { if (gx > growth_limit_bits<R>()) warn = true; }
+        if constexpr (kMonitor) { if (gx > growth_limit_bits<R>()) grow = true; }
         R pw[W], mw[W], p0, m0, ml;      // pw[w], mw[w]: the two numbers of wave w (valid for the group heads while unfolding)
         close_root(sw[0], sm.xbc[parity][0], sm.xbc[parity][1], sm.xbc[parity][2], p0, m0, ml);
         pw[0] = p0; mw[0] = ml;
@@ -1019,6 +1020,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         below = tot < t2 - band ? true : (tot > t2 + band ? false : sqrt_(tot) < a.tol);
       }
       converged = status == FS_OK && below;
+      // The warning is about the system the level's result comes from - the Jacobian at the accepted iterate.  An iterate on the
+      // way there may pass a small pivot by accident (a soak draw did: a three-node reach behind a reservoir, condition number
+      // 3e4 throughout, |u3| > 2^10 once in the 12 iterations of its first level); Newton does not remember that.
+      if (converged && grow) warn = true;
 
       FS_T(5);
       // ================= 5. separators down the tree, local back-substitution ============

@@ -432,17 +432,17 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
             const int gtop = __builtin_amdgcn_readlane(gx, 63);
             if (lane == 0) {
               sm.xtot = tot;
-              if (gtop > growth_limit_bits<R>()) sm.xwarn = 1;
+              sm.xwarn = gtop > growth_limit_bits<R>() ? 1 : 0;
             }
           }
           __syncthreads();
           const R tot = sm.xtot;
           if (sm.xflag != 0) status = sm.xflag;
-          if (sm.xwarn != 0) warn = true;
           if (!(tot <= finite_max<R>())) status = FS_NAN;
           const R err = sqrt_(tot);
           if (a.trace && t == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
           converged = status == FS_OK && err < a.tol;
+          if (converged && sm.xwarn != 0) warn = true;          // (the system at the accepted iterate: see the step kernel)
         }
       }   // sweeps
       __syncthreads();                              // this iteration's stores before the next iteration's loads

@@ -38,6 +38,14 @@ def label(c):
     return f"{i:02d}-{m['family']}-N{m['N']}-{m['ds_kind']}"
 
 
+def froude_max(fx):
+    """largest Froude number of the reference's own history (trapezoid family: main channel of the section)"""
+    b, ms = fx["geo_b_main"], fx["geo_m_main"]
+    h, Q = fx["depth"], fx["flow"]
+    A, T = (b + ms * h) * h, b + 2.0 * ms * h
+    return float(np.max(np.abs(Q) / A / np.sqrt(9.81 * A / T)))
+
+
 def compare(res_depth, res_flow, res_iters, fx, m):
     hn, Qb = m["h_n"], m["Qb"]
     assert rel_err(res_depth, fx["depth"], 1e-3 * hn) <= TOL
@@ -85,8 +93,15 @@ def test_kernel_reproduces_the_reference(case):
     for mode in modes:
         with batch_from_problems([p], mode=mode, history=True) as b:
             b.step(p.nt - 1)
-            assert np.all(b.status() == 0), (mode, b.status())
+            st = int(b.status()[0])
             h, Q = b.history_arrays(0, p.nt)
+            if st == 4 and m["family"] != "polyline":
+                # FS_ILL_CONDITIONED, a warning (include/flowsim_abi.h): the rule is "1e-8 or flagged", and a flag must have its
+                # reason - a random draw that runs supercritical (a soak found one: 0.5 m of water at 7 m/s, Froude 3)
+                assert froude_max(fx) > 0.9, (mode, froude_max(fx))
+                assert rel_err(h[:, 0], fx["depth"], 1e-3 * m["h_n"]) <= 1e-6 and rel_err(Q[:, 0], fx["flow"], 1e-3 * m["Qb"]) <= 1e-6
+                continue
+            assert st == 0, (mode, st)
             compare(h[:, 0], Q[:, 0], b.iterations(0, p.nt)[:, 0], fx, m)
 
 
