@@ -117,7 +117,7 @@ enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3,
         * ill-conditioned - in practice supercritical flow (v > c) over a long stretch, where one boundary condition per end
         * is not what the flow takes.  The on-chip elimination does not pivot; it watches how strongly the first unknown of any
         * segment of rows depends on the last one (a product of super-diagonal / pivot ratios that decays for subcritical
-        * flow) and raises this status when that exceeds 2^10: results may then differ from another solver's (the reference's
+        * flow) and raises this status when that exceeds 2^10 in the iteration that accepts a level: results may then differ from another solver's (the reference's
         * SuperLU included) by more than the 1e-8 this library otherwise keeps.  The reference's counterpart is the
         * `diagnos` check of run(), ValueError("Jacobian is ill-conditioned (rcond too small)"), preissmann.py:139-144, and
         * the Froude diagnosis of check_criticality (:179-198).  Raised by the kernels compiled with diagnostics: every batch
