@@ -118,6 +118,9 @@
                          // (16 W live doubles).  Measured on 65 536 x 4 096 (profiles/round3/second_wave_per_simd.md): W = 8 (the (8, 8)
                          // shape, two waves per SIMD) 7.9e6 -> 9.8e6 (the per-thread fold spills at 256 registers); W = 4 (the flagship
                          // (16, 4) shape) 1.072e7 -> 1.058e7: with four segments the per-thread fold has the shorter dependent chain
+#ifndef FS_PREFETCH_DOWN
+#define FS_PREFETCH_DOWN 1   // multi-wave kernels without diagnostics: this many of the wave's top tree records (levels 5, 4, 3) are requested
+#endif                       // ahead of the cross-wave barrier instead of after the cross-wave step
 #ifndef FS_PRIME
 #define FS_PRIME 0      // 1: the level constants of a launch's first level come from the acceptance block of the loop (a priming pass
 #endif                   // through it) instead of from a second instance of that code ahead of the loop.  Not needed: with
@@ -886,6 +889,21 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         if constexpr (kMonitor) sm.xg[parity][wave] = gi;
       }
       FS_T(2);
+      // the wave's own top tree records for the way down (step 5), requested ahead of the barrier: their LDS latency passes
+      // during the cross-wave step instead of after it (FS_PREFETCH_DOWN levels; the wave wrote them itself, in order)
+      auto load_rec_early = [&](auto lc) __attribute__((always_inline)) {
+        constexpr int l = decltype(lc)::value;
+        Elim<R> e;
+        const int slot = (64 - (64 >> l)) + (ln >> (l + 1));
+        const R *p = &sm.tree[wave][0][slot];
+        e.A1 = p[0 * 64]; e.A2 = p[1 * 64]; e.A3 = p[2 * 64]; e.rc = p[3 * 64];
+        return e;
+      };
+      constexpr int kPre = (W > 1 && M >= 8 && !DIAG) ? FS_PREFETCH_DOWN : 0;
+      Elim<R> pre5, pre4, pre3;
+      if constexpr (kPre >= 1) pre5 = load_rec_early(std::integral_constant<int, 5>{});
+      if constexpr (kPre >= 2) pre4 = load_rec_early(std::integral_constant<int, 4>{});
+      if constexpr (kPre >= 3) pre3 = load_rec_early(std::integral_constant<int, 3>{});
       __syncthreads();
       FS_T(3);
 
@@ -1052,10 +1070,12 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         using I3 = std::integral_constant<int, 3>; using I2 = std::integral_constant<int, 2>;
         using I1 = std::integral_constant<int, 1>; using I0 = std::integral_constant<int, 0>;
         __builtin_amdgcn_sched_barrier(0);
-        const Elim<R> r5 = load_rec(I5{}), r4 = load_rec(I4{});
+        Elim<R> r5, r4, r3;
+        if constexpr (kPre >= 1) r5 = pre5; else r5 = load_rec(I5{});
+        if constexpr (kPre >= 2) r4 = pre4; else r4 = load_rec(I4{});
         asm volatile("" ::: "memory");
         down_level(I5{}, r5);
-        const Elim<R> r3 = load_rec(I3{});
+        if constexpr (kPre >= 3) r3 = pre3; else r3 = load_rec(I3{});
         asm volatile("" ::: "memory");
         down_level(I4{}, r4);
         const Elim<R> r2 = load_rec(I2{});

@@ -22,42 +22,44 @@ t0 = time.perf_counter(); h3, Q3 = bt.state(); t_down_fresh = time.perf_counter(
 assert np.all(bt.status() == 0) and np.array_equal(h2, h3) and np.array_equal(Q2, Q3)
 hx, Qx = bt.state(); assert np.all(np.isfinite(hx)) and abs(hx.mean() / h.mean() - 1) < 0.5
 gb = B * N * 8 * 2 / 1e9
-# the same work as two stream-ordered halves (two handles, two streams, two host threads: ctypes releases the GIL): half B uploads
-# while half A steps, half A downloads while half B steps
-import threading
+# the same work as stream-ordered blocks of reaches (flowsim_amd.pipeline): block i + 1 uploads while block i steps, block i - 1
+# downloads meanwhile
+from flowsim_amd.pipeline import step_pipelined
 bt.close(); del h3, Q3, hx, Qx
-half = B // 2
 
 
-def make(lo):
-    x = PreissmannBatch(half, N, K + 1, section_mode="rect_uniform")
-    x.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); x.set_geometry_uniform(b_[lo:lo + half], n_[lo:lo + half], S0[lo:lo + half] * L, np.zeros(half))
-    x.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb[lo:lo + half], K + 1, 600.0)))
-    x.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0[lo:lo + half], bed_level=np.zeros(half))))
+def make(lo, nb):
+    x = PreissmannBatch(nb, N, K + 1, section_mode="rect_uniform")
+    x.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); x.set_geometry_uniform(b_[lo:lo + nb], n_[lo:lo + nb], S0[lo:lo + nb] * L, np.zeros(nb))
+    x.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb[lo:lo + nb], K + 1, 600.0)))
+    x.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0[lo:lo + nb], bed_level=np.zeros(nb))))
     x.sync()
     return x
 
 
-halves = [make(0), make(half)]
-
-
-def work(i):
-    lo = i * half
-    halves[i].set_state(h[lo:lo + half], Q[lo:lo + half]); halves[i].step(K, sync=True)
-    halves[i].state(out=(h2[lo:lo + half], Q2[lo:lo + half]))
-
-
 ref_h, ref_Q = h2.copy(), Q2.copy()
-h2[:] = 0; Q2[:] = 0
-t0 = time.perf_counter()
-ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-ths[0].start(); time.sleep(0.02); ths[1].start()           # (half B starts once half A's upload is under way)
-for th in ths:
-    th.join()
-t_pipe = time.perf_counter() - t0
-assert np.array_equal(h2, ref_h) and np.array_equal(Q2, ref_Q)          # same bits as the one-batch run
+
+
+def pipelined(n_chunks):
+    nb = B // n_chunks
+    parts = [make(i * nb, nb) for i in range(n_chunks)]
+    h2[:] = 0; Q2[:] = 0
+    t0 = time.perf_counter()
+    step_pipelined(parts, h, Q, K, out=(h2, Q2))
+    t = time.perf_counter() - t0
+    assert np.array_equal(h2, ref_h) and np.array_equal(Q2, ref_Q)          # same bits as the one-batch run
+    for x in parts:
+        x.close()
+    return t
+
+
+chunk_counts = [int(c) for c in os.environ.get("FS_PCIE_CHUNKS", "2,4,8,16").split(",") if B % int(c) == 0 and B // int(c) >= 1]
+t_chunks = {c: pipelined(c) for c in chunk_counts}
+t_pipe = t_chunks.get(2, min(t_chunks.values()))
 print(json.dumps({"reaches": B, "nodes": N, "levels": K, "upload_s": t_up, "step_s": t_step, "download_s": t_down,
                   "upload_GBps": gb / t_up, "download_GBps": gb / t_down, "download_into_fresh_buffers_s": t_down_fresh,
                   "download_into_fresh_buffers_GBps": gb / t_down_fresh, "device_resident_rts_per_s": B * K / t_step,
                   "pcie_inclusive_rts_per_s": B * K / (t_up + t_step + t_down),
-                  "two_halves_pipelined_s": t_pipe, "pcie_inclusive_two_halves_rts_per_s": B * K / t_pipe}))
+                  "two_halves_pipelined_s": t_pipe, "pcie_inclusive_two_halves_rts_per_s": B * K / t_pipe,
+                  "pipelined_chunks_s": {str(c): t for c, t in t_chunks.items()},
+                  "pcie_inclusive_pipelined_rts_per_s": {str(c): B * K / t for c, t in t_chunks.items()}}))
