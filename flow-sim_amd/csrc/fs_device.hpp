@@ -843,6 +843,18 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
   return __int_as_float(dpp_mov<CTRL>(__float_as_int(v)));
 }
+// the same move into the lanes of the banks (groups of 4 lanes within a row of 16) in BANKS only; the others keep `old`
+template <int CTRL, int BANKS> __device__ __forceinline__ int dpp_mov_banks(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xF, BANKS, false);
+}
+template <int CTRL, int BANKS> __device__ __forceinline__ double dpp_mov_banks(double old, double v) {
+  const int lo = dpp_mov_banks<CTRL, BANKS>(__double2loint(old), __double2loint(v));
+  const int hi = dpp_mov_banks<CTRL, BANKS>(__double2hiint(old), __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int BANKS> __device__ __forceinline__ float dpp_mov_banks(float old, float v) {
+  return __int_as_float(dpp_mov_banks<CTRL, BANKS>(__float_as_int(old), __float_as_int(v)));
+}
 // value of lane - D for lanes whose low log2(2D) bits are all ones (others: unspecified)
 template <int D, typename R> __device__ __forceinline__ R tree_from_below(R v) {
 #if FS_DPP

@@ -118,6 +118,12 @@
                          // (16 W live doubles).  Measured on 65 536 x 4 096 (profiles/round3/second_wave_per_simd.md): W = 8 (the (8, 8)
                          // shape, two waves per SIMD) 7.9e6 -> 9.8e6 (the per-thread fold spills at 256 registers); W = 4 (the flagship
                          // (16, 4) shape) 1.072e7 -> 1.058e7: with four segments the per-thread fold has the shorter dependent chain
+#ifndef FS_TREE_REGS
+#define FS_TREE_REGS 0       // flagship shapes: the in-wave tree's records stay in registers (6 levels x 4 numbers, valid in the lane that survives
+#endif                       // its level) and come back on the way down by DPP broadcasts / readlanes instead of through LDS slots
+#ifndef FS_RC_EARLY
+#define FS_RC_EARLY 0        // flagship shapes: the continuity residuals the back-substitution needs are recomputed inside the cross-wave step
+#endif
 #ifndef FS_PREFETCH_DOWN
 #define FS_PREFETCH_DOWN 1   // multi-wave kernels without diagnostics: this many of the wave's top tree records (levels 5, 4, 3) are requested
 #endif                       // ahead of the cross-wave barrier instead of after the cross-wave step
@@ -861,13 +867,17 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       __builtin_amdgcn_sched_barrier(0);   // phases are not interleaved: it only costs registers (measured around the down-sweep: +5 %)
 #endif
       // ================= 3. in-wave tree (up-sweep) =================
+      constexpr bool kTreeRegs = FS_TREE_REGS && W > 1 && M >= 8 && !DIAG;
+      Elim<R> rec[kTreeRegs ? 6 : 1];
       auto up_level = [&](auto lc) __attribute__((always_inline)) {
         constexpr int l = decltype(lc)::value;
         constexpr int d = 1 << l;
         const Seg<R> left = seg_from_below<d>(seg);
         Seg<R> mg; Elim<R> e;
         merge(left, seg, mg, e);
-        if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+        if constexpr (kTreeRegs) {
+          rec[l] = e;
+        } else if ((lane & (2 * d - 1)) == (2 * d - 1)) {
           const int slot = (64 - (64 >> l)) + (ln >> (l + 1));
           R *p = &sm.tree[wave][0][slot];
           p[0 * 64] = e.A1; p[1 * 64] = e.A2; p[2 * 64] = e.A3; p[3 * 64] = e.rc;
@@ -899,13 +909,26 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         e.A1 = p[0 * 64]; e.A2 = p[1 * 64]; e.A3 = p[2 * 64]; e.rc = p[3 * 64];
         return e;
       };
-      constexpr int kPre = (W > 1 && M >= 8 && !DIAG) ? FS_PREFETCH_DOWN : 0;
+      constexpr int kPre = (W > 1 && M >= 8 && !DIAG && !kTreeRegs) ? FS_PREFETCH_DOWN : 0;
       Elim<R> pre5, pre4, pre3;
       if constexpr (kPre >= 1) pre5 = load_rec_early(std::integral_constant<int, 5>{});
       if constexpr (kPre >= 2) pre4 = load_rec_early(std::integral_constant<int, 4>{});
       if constexpr (kPre >= 3) pre3 = load_rec_early(std::integral_constant<int, 3>{});
       __syncthreads();
       FS_T(3);
+      // rc of the lane's rows for the back-substitution (step 5) does not depend on the solve: computed here, its instructions
+      // fill the waits of the cross-wave step (a chain of dependent merges and reciprocals) instead of lengthening step 5
+      constexpr bool kRcEarly = FS_RC_EARLY && Geo::kConstT && FS_LAUNDER_BACK && W > 1 && M >= 8 && !DIAG && !RAGGED;
+      R rcE[kRcEarly ? M - 1 : 1];
+      if constexpr (kRcEarly) {
+        asm volatile("" : "+v"(kco));
+        kcb = &sm.kc[0][0][0] + kco;
+#pragma unroll
+        for (int j = 0; j <= M; ++j) asm volatile("" : "+v"(h[j]), "+v"(Q[j]));
+#pragma unroll
+        for (int j = 0; j + 1 < M; ++j)
+          rcE[j] = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
+      }
 
       // ================= 4. across waves: fold, close with the upstream row, unfold =================
       R tot = R(0);
@@ -1070,6 +1093,27 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         using I3 = std::integral_constant<int, 3>; using I2 = std::integral_constant<int, 2>;
         using I1 = std::integral_constant<int, 1>; using I0 = std::integral_constant<int, 0>;
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kTreeRegs) {
+          // the group's record from the group's last lane: readlane (the wave, its halves), row_newbcast (rows of 16, halves of a
+          // row through the bank mask), quad_perm (quads, pairs)
+          auto fetch = [&](auto lc2, R v) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc2)::value;
+            if constexpr (l == 5) return read_lane(v, 63);
+            else if constexpr (l == 4) { const R lo = read_lane(v, 31), hi = read_lane(v, 63); return lane < 32 ? lo : hi; }
+            else if constexpr (l == 3) return dpp_mov<0x15F>(v);
+            else if constexpr (l == 2) return dpp_mov_banks<0x15F, 0xC>(dpp_mov_banks<0x157, 0x3>(R(0), v), v);
+            else if constexpr (l == 1) return dpp_mov<0xFF>(v);
+            else return dpp_mov<0xF5>(v);
+          };
+          auto rec_of = [&](auto lc2) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc2)::value;
+            Elim<R> e;
+            e.A1 = fetch(lc2, rec[l].A1); e.A2 = fetch(lc2, rec[l].A2); e.A3 = fetch(lc2, rec[l].A3); e.rc = fetch(lc2, rec[l].rc);
+            return e;
+          };
+          down_level(I5{}, rec_of(I5{})); down_level(I4{}, rec_of(I4{})); down_level(I3{}, rec_of(I3{}));
+          down_level(I2{}, rec_of(I2{})); down_level(I1{}, rec_of(I1{})); down_level(I0{}, rec_of(I0{}));
+        } else {
         Elim<R> r5, r4, r3;
         if constexpr (kPre >= 1) r5 = pre5; else r5 = load_rec(I5{});
         if constexpr (kPre >= 2) r4 = pre4; else r4 = load_rec(I4{});
@@ -1088,6 +1132,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         asm volatile("" ::: "memory");
         down_level(I1{}, r1);
         down_level(I0{}, r0);
+        }
         asm volatile("" : "+v"(pL), "+v"(mR));
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1100,7 +1145,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
       // The update is kept pending in dh/dQ (they take the registers the elimination records free up):
       // the accepted iterate must still be intact for the level-constant pass below.
-      if (Geo::kConstT && FS_LAUNDER_BACK) {
+      if (Geo::kConstT && FS_LAUNDER_BACK && !kRcEarly) {
         // The continuity residuals are recomputed below on purpose (one value per node less to keep
         // across the solve).  Hide the operands so that common-subexpression elimination does not
         // resurrect the fold's copies of dQ / kc0 and keep 2 values per node alive instead.
@@ -1114,6 +1159,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         auto i2t_of = [&](int j) { return Geo::kConstT ? i2tc : iTn[j]; };
         // rc of row j for the link p_{j+1} = rc_j - m_j: minus the continuity residual of cell j, 0 beyond the cells
         auto rc_of = [&](int j) __attribute__((always_inline)) {
+          if constexpr (kRcEarly) return rcE[j];
           if (Geo::kConstT) {
             const R v = -(geo.terms_T() * (h[j] + h[j + 1]) * r2dt + cq * (Q[j + 1] - Q[j]) + kcb[(0 * M + j) * T]);
             return (RAGGED && s0 + j >= NC) ? R(0) : v;
