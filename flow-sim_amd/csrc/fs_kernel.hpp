@@ -49,6 +49,9 @@
 #ifndef FS_LONG_RECOMPUTE
 #define FS_LONG_RECOMPUTE 1   // multi-pass kernel, uniform sections: level constants recomputed per sweep instead of stored (fs_long.hpp)
 #endif
+#ifndef FS_LONG_COALESCE
+#define FS_LONG_COALESCE 1    // multi-pass kernel: state loads and stores with consecutive lanes on consecutive nodes, transposed through LDS
+#endif
 #ifndef FS_LONG_WPE
 #define FS_LONG_WPE 2
 #endif

@@ -27,7 +27,11 @@
 
 namespace fs {
 
-template <typename R, int W> struct SmemLong {
+template <typename R, int W, int M> struct SmemLong {
+  // per-wave staging of the wave's 64 M (+ 1) nodes of a pass: global memory is read and written with consecutive lanes on
+  // consecutive nodes, a lane takes its M + 1 consecutive nodes from here (one pad per 8 numbers: the lanes' chunks start in
+  // different banks)
+  R stage[W][2][FS_LONG_COALESCE ? 64 * M + 8 * M + 8 : 1];
   R tree[W][4][64];        // in-wave tree records of the pass being worked on
   R xtree[4][64];          // records of the top tree over the (pass, wave) segments (wave 0)
   R xseg[64][8];           // one segment per (pass, wave)
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
   // evaluations of ~40 instructions) instead of being fetched from a scratch: 16 B instead of 32 B per node and sweep for a kernel
   // that is bound by HBM.  Same expressions as the stored ones, hence the same bits.
   constexpr bool kRecompute = FS_LONG_RECOMPUTE && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM);
-  __shared__ SmemLong<R, W> sm;
+  __shared__ SmemLong<R, W, M> sm;
 
   const int reach = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -110,6 +114,71 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
       const int node = min(g0 + j, N - 1);
       h[j] = hs[base + node]; Q[j] = Qs[base + node];
     }
+  };
+  // The same nodes with consecutive lanes on consecutive nodes (a lane's own M + 1 nodes are 8 M bytes apart from its neighbour's:
+  // every load instruction of load_nodes touches 64 separate 64-byte segments, and the texture addresser was busy 82 % of the
+  // kernel's time with them, profiles/round3/long_mem.txt), transposed through the wave's staging buffer.  LDS executes a wave's
+  // instructions in order; the fences keep the compiler from moving the reads over the writes.
+  constexpr bool kCo = FS_LONG_COALESCE != 0;
+  auto pad = [](int i) { return i + (i >> 3); };
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  auto load_nodes_co = [&](const R *hs, const R *Qs, int p, R(&h)[M + 1], R(&Q)[M + 1]) __attribute__((always_inline)) {
+    const int wb = p * C + wave * (64 * M);                   // first node of this wave in this pass
+    auto one = [&](const R *src, R *st, R(&out)[M + 1]) __attribute__((always_inline)) {
+      R tv[M + 1];
+#pragma unroll
+      for (int k = 0; k < M; ++k) tv[k] = src[base + min(wb + lane + 64 * k, N - 1)];
+      if (lane == 0) tv[M] = src[base + min(wb + 64 * M, N - 1)];     // the node the wave shares with its right neighbour
+#pragma unroll
+      for (int k = 0; k < M; ++k) st[pad(lane + 64 * k)] = tv[k];
+      if (lane == 0) st[pad(64 * M)] = tv[M];
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j <= M; ++j) out[j] = st[pad(lane * M + j)];
+    };
+    if constexpr (FS_LONG_COALESCE == 2) {      // one array after the other (half the numbers in flight)
+      one(hs, sm.stage[wave][0], h);
+      one(Qs, sm.stage[wave][1], Q);
+      wave_sync();
+    } else {
+    R *const sh = sm.stage[wave][0], *const sq = sm.stage[wave][1];
+    R th[M + 1], tq[M + 1];
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const int node = min(wb + lane + 64 * k, N - 1);
+      th[k] = hs[base + node]; tq[k] = Qs[base + node];
+    }
+    if (lane == 0) {                                          // the node the wave shares with its right neighbour
+      const int node = min(wb + 64 * M, N - 1);
+      th[M] = hs[base + node]; tq[M] = Qs[base + node];
+    }
+#pragma unroll
+    for (int k = 0; k < M; ++k) { sh[pad(lane + 64 * k)] = th[k]; sq[pad(lane + 64 * k)] = tq[k]; }
+    if (lane == 0) { sh[pad(64 * M)] = th[M]; sq[pad(64 * M)] = tq[M]; }
+    wave_sync();
+#pragma unroll
+    for (int j = 0; j <= M; ++j) { h[j] = sh[pad(lane * M + j)]; Q[j] = sq[pad(lane * M + j)]; }
+    wave_sync();
+    }
+  };
+  // values of the lane's nodes g0 .. g0 + M - 1 to hd / Qd (nodes beyond the reach are not written)
+  auto store_nodes_co = [&](R *hd, R *Qd, int p, const R *hv, const R *Qv) __attribute__((always_inline)) {
+    const int wb = p * C + wave * (64 * M);
+    R *const sh = sm.stage[wave][0], *const sq = sm.stage[wave][1];
+#pragma unroll
+    for (int j = 0; j < M; ++j) { sh[pad(lane * M + j)] = hv[j]; sq[pad(lane * M + j)] = Qv[j]; }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const int e = wb + lane + 64 * k;
+      const R x = sh[pad(lane + 64 * k)], y = sq[pad(lane + 64 * k)];
+      if (e < N) { hd[base + e] = x; Qd[base + e] = y; }
+    }
+    wave_sync();
   };
   auto kc_at = [&](int i, int p, int c) __attribute__((always_inline)) -> R & { return kcg[(size_t)i * RP + ((size_t)p * M + c) * T + t]; };
   // the four constants of cell (node, node + 1) from the node terms and unknowns of level k (one source for the stored and the recomputed ones)
@@ -169,9 +238,9 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
             continue;
           }
           R h[M + 1], Q[M + 1];
-          load_nodes(a.hg, a.Qg, g0, h, Q);
+          if constexpr (kCo) load_nodes_co(a.hg, a.Qg, p, h, Q); else load_nodes(a.hg, a.Qg, g0, h, Q);
           R hk_[kRecompute ? M + 1 : 1], Qk_[kRecompute ? M + 1 : 1];     // accepted state of level k at the lane's nodes
-          if constexpr (kRecompute) load_nodes(a.hk, a.Qk, g0, hk_, Qk_);
+          if constexpr (kRecompute) { if constexpr (kCo) load_nodes_co(a.hk, a.Qk, p, hk_, Qk_); else load_nodes(a.hk, a.Qk, g0, hk_, Qk_); }
           if (phase == 1) __syncthreads();          // every lane holds its nodes before any lane stores updated ones
 
           // ---- boundary rows (boundary.py:56-242) ----
@@ -349,10 +418,11 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
             const bool last = step == a.n_steps - 1;
             R *const hh_p = a.hist_h ? a.hist_h + ((size_t)level * a.B + reach) * NS + g0 : nullptr;
             R *const hQ_p = a.hist_h ? a.hist_Q + ((size_t)level * a.B + reach) * NS + g0 : nullptr;
+            if constexpr (kCo) { if (last || kRecompute) store_nodes_co(a.hk, a.Qk, p, h, Q); }
 #pragma unroll
             for (int j = 0; j < M; ++j) {
               if (g0 + j < N) {
-                if (last || kRecompute) { a.hk[base + g0 + j] = h[j]; a.Qk[base + g0 + j] = Q[j]; }
+                if (!kCo && (last || kRecompute)) { a.hk[base + g0 + j] = h[j]; a.Qk[base + g0 + j] = Q[j]; }
                 if (hh_p) { hh_p[j] = h[j]; hQ_p[j] = Q[j]; }
               }
             }
@@ -369,9 +439,16 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
             }
             if constexpr (!kRecompute) write_level_constants(p, g0, h, Q);
           }
+          if constexpr (kCo) {
+            R hn[M], Qn[M];
+#pragma unroll
+            for (int j = 0; j < M; ++j) { hn[j] = h[j] + dh[j]; Qn[j] = Q[j] + dQ[j]; }
+            store_nodes_co(a.hg, a.Qg, p, hn, Qn);
+          } else {
 #pragma unroll
           for (int j = 0; j < M; ++j)
             if (g0 + j < N) { a.hg[base + g0 + j] = h[j] + dh[j]; a.Qg[base + g0 + j] = Q[j] + dQ[j]; }
+          }
         }   // passes
 
         if (phase == 0) {

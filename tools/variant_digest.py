@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flow-sim_amd"))
 from flowsim_amd import BoundarySpec, PreissmannBatch, _abi as A
 from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
-B, N, K = 96, 4096, 6
+B, N, K = 96, int(os.environ.get("FS_DIGEST_NODES", "4096")), 6
 b_, n_, S0, Qb = c3_reach_parameters(0, B); hn = normal_depth_rect(b_, n_, S0, Qb); L = (N - 1) * 250.0
 with PreissmannBatch(B, N, K + 1, section_mode="rect_uniform") as x:
     x.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); x.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
