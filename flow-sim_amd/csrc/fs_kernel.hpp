@@ -49,6 +49,9 @@
 #ifndef FS_LONG_RECOMPUTE
 #define FS_LONG_RECOMPUTE 1   // multi-pass kernel, uniform sections: level constants recomputed per sweep instead of stored (fs_long.hpp)
 #endif
+#ifndef FS_LONG_PREFETCH
+#define FS_LONG_PREFETCH 0    // multi-pass kernel: the next pass's lines requested into L2 a pass ahead
+#endif
 #ifndef FS_LONG_COALESCE
 #define FS_LONG_COALESCE 1    // multi-pass kernel: state loads and stores with consecutive lanes on consecutive nodes, transposed through LDS
 #endif

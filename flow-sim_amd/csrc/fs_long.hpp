@@ -215,6 +215,8 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
   }
   __syncthreads();
 
+  constexpr bool kPf = FS_LONG_PREFETCH != 0 && kCo;
+  int pf[4] = {0, 0, 0, 0};
   for (int step = 0; step < a.n_steps && status == FS_OK; ++step) {
     const int level = a.level0 + step + 1;
     if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
@@ -241,6 +243,19 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
           if constexpr (kCo) load_nodes_co(a.hg, a.Qg, p, h, Q); else load_nodes(a.hg, a.Qg, g0, h, Q);
           R hk_[kRecompute ? M + 1 : 1], Qk_[kRecompute ? M + 1 : 1];     // accepted state of level k at the lane's nodes
           if constexpr (kRecompute) { if constexpr (kCo) load_nodes_co(a.hk, a.Qk, p, hk_, Qk_); else load_nodes(a.hk, a.Qk, g0, hk_, Qk_); }
+          if constexpr (kPf) {
+            // the lines of the next pass's state, requested a pass ahead (one dword per 64 bytes, results unused): when the
+            // pass gets there its loads find them in L2.  The four registers stay reserved until the loads have landed -
+            // the real loads above are younger than the last pass's requests and have been waited for.
+            asm volatile("" :: "v"(pf[0]), "v"(pf[1]), "v"(pf[2]), "v"(pf[3]));
+            int pn = p + 1;
+            if (pn >= P || pn * C > NC) pn = phase == 0 ? 0 : -1;
+            if (pn >= 0) {
+              const size_t o = base + min(pn * C + wave * (64 * M) + lane * 8, N - 1);
+              pf[0] = *reinterpret_cast<const volatile int *>(a.hg + o); pf[1] = *reinterpret_cast<const volatile int *>(a.Qg + o);
+              if constexpr (kRecompute) { pf[2] = *reinterpret_cast<const volatile int *>(a.hk + o); pf[3] = *reinterpret_cast<const volatile int *>(a.Qk + o); }
+            }
+          }
           if (phase == 1) __syncthreads();          // every lane holds its nodes before any lane stores updated ones
 
           // ---- boundary rows (boundary.py:56-242) ----

@@ -6,6 +6,7 @@ bash tools/profile.sh irr_f64 --workload irr --reaches 8192 --steps 16 --warmup 
 bash tools/profile.sh c4_f64 --workload c4 --reaches 32768 --steps 16 --warmup 2 && echo "c4 done"
 bash tools/profile.sh long_f64 --nodes 16384 --reaches 8192 --steps 8 --warmup 2 && echo "long done"
 FS_KERNEL_SHAPE=8,8 bash tools/profile.sh c3_f64_8x8 --reaches 65536 --steps 20 --warmup 5 && echo "8x8 done"
+mkdir -p gpurun_out/prof/markers
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --marker-trace --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof/markers -- python3 $OLDPWD/tools/bench_pcie.py 8192 > $OLDPWD/gpurun_out/prof/markers/bench.json 2> $OLDPWD/gpurun_out/prof/markers/err.txt ); echo "markers rc $?"
 {
 echo -n "c4 shared table:    "; ARGS="--workload c4 --reaches 32768 --steps 16 --warmup 2" bash tools/run_once.sh
