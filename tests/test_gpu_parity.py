@@ -404,6 +404,37 @@ def test_reaches_longer_than_the_lane_grid_against_the_c_oracle(N, mode):
         assert np.array_equal(c.hydrographs()[:, :, 0], hyd[:, :, 1])
 
 
+def test_long_reaches_of_different_lengths_in_one_batch():
+    """Seven channels of 4 097 ... 9 999 nodes in ONE batch (per-reach node counts, steps and boundary kinds) on the multi-pass
+    kernel: its state loads and stores run with consecutive lanes on consecutive nodes and are transposed through LDS, so the
+    clamped copies beyond a reach's last node, passes that are half empty and waves that hold no node at all each occur here -
+    seeded lengths around the pass (2 048 rows) and wave (512 rows) boundaries.  Pivoted C oracle, 1e-8, equal Newton counts."""
+    from fixture_batch import hetero_batch_from_problems
+    from oracle import c_oracle
+    from synth import rect_problem
+    rng = np.random.default_rng(4242)
+    lengths = [4097, 9999, 2048 * 3 + 1, 2048 * 4, 512 * 9 + 1, int(rng.integers(4200, 9000)), int(rng.integers(4200, 9000))]
+    probs = []
+    for s, N in enumerate(lengths):
+        q = rect_problem(N, seed=1300 + s, n_steps=3, dt=float(rng.choice([300.0, 600.0, 900.0])), dx=float(rng.choice([125.0, 250.0])),
+                         theta=float(rng.uniform(0.55, 0.9)))
+        if s % 2:
+            q.geo["m_main"][:] = 1.0
+        probs.append(q)
+    with hetero_batch_from_problems(probs) as b:
+        b.step(3)
+        assert np.all(b.status() == 0)
+        from flowsim_amd import _abi as A_
+        assert A_.kernel_table()[b.kernel_index()]["long_reach"] == 1
+        h, Q = b.history_arrays()
+        its = b.iterations()
+    for i, q in enumerate(probs):
+        out = c_oracle.run(q)
+        assert rel_err(h[:, i, :q.N], out["depth"], 1e-3) <= TOL, lengths[i]
+        assert rel_err(Q[:, i, :q.N], out["flow"], 1.0) <= TOL, lengths[i]
+        assert np.array_equal(its[:, i], out["iters"]), lengths[i]
+
+
 def test_gerd_roseires_at_a_spatial_step_of_25_m():
     """cases/gerd_roseires refined to dx = 25 m: 4 817 nodes of compound sections with curvature and the gate curve - more than
     a table kernel keeps on chip; against the C oracle over the first levels"""
