@@ -28,6 +28,10 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL fails with "hipIpcGetMemHandle: invalid argument" otherwise); the
+# boxes export it already - kept here so that a bare `torch.distributed.run bench.py` from a clean shell works as well
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "flow-sim_amd"))
 sys.path.insert(0, ROOT)
