@@ -48,6 +48,10 @@ template <int OP> __global__ __launch_bounds__(256) void k(double *out, unsigned
       if (OP == 20) asm volatile("v_fma_f64 %0, %0, %1, %0\n\tv_accvgpr_write_b32 a2, %2" : "+v"(a[i]) : "v"(seed), "v"(f[i]) : "a2");
       if (OP == 21) asm volatile("v_fma_f64 %0, %0, %1, %0\n\tds_write_b64 %2, %0" : "+v"(a[i]) : "v"(seed), "v"(ldsaddr) : "memory");
       if (OP == 22) asm volatile("v_mov_b64 %0, %0" : "+v"(a[i]));
+      if (OP == 23) asm volatile("s_mov_b64 exec, 1\n\tds_read_b64 %0, %1\n\ts_mov_b64 exec, -1" : "=v"(a[i]) : "v"(ldsaddr));           // one lane active
+      if (OP == 24) asm volatile("s_mov_b64 exec, 0xffff\n\tds_read_b64 %0, %1\n\ts_mov_b64 exec, -1" : "=v"(a[i]) : "v"(ldsaddr));      // sixteen lanes active
+      if (OP == 25) asm volatile("ds_read_b64 %0, %1" : "=v"(a[i]) : "v"(0u));                                                                // every lane the same address
+
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -77,15 +81,15 @@ int main() {
   double f = run<0>("v_fma_f64", out, cyc);
   const char *n[] = {"", "v_mul_f64", "v_add_f64", "v_rcp_f64", "v_log_f32", "v_exp_f32", "cvt f64>f32>f64 pair", "v_cvt_f64_f32 (same dst)", "v_rcp_f32", "v_mul_f32",
                      "accvgpr write+read pair", "v_mov_b32_dpp", "v_rsq_f64", "v_cndmask_b32 vcc", "v_cndmask_b32 sgpr", "accvgpr_read + mul_f32", "v_mov_b32", "readlane + mul_f32", "ds_read_b64", "ds_write_b64",
-                     "fma + accvgpr_write", "fma + ds_write_b64", "v_mov_b64"};
-  double r[23];
+                     "fma + accvgpr_write", "fma + ds_write_b64", "v_mov_b64", "ds_read_b64 1 lane", "ds_read_b64 16 lanes", "ds_read_b64 broadcast"};
+  double r[26];
   r[1] = run<1>(n[1], out, cyc); r[2] = run<2>(n[2], out, cyc); r[3] = run<3>(n[3], out, cyc); r[4] = run<4>(n[4], out, cyc);
   r[5] = run<5>(n[5], out, cyc); r[6] = run<6>(n[6], out, cyc); r[7] = run<7>(n[7], out, cyc); r[8] = run<8>(n[8], out, cyc);
   r[9] = run<9>(n[9], out, cyc); r[10] = run<10>(n[10], out, cyc); r[11] = run<11>(n[11], out, cyc); r[12] = run<12>(n[12], out, cyc);
   r[13] = run<13>(n[13], out, cyc); r[14] = run<14>(n[14], out, cyc); r[15] = run<15>(n[15], out, cyc); r[16] = run<16>(n[16], out, cyc);
   r[17] = run<17>(n[17], out, cyc); r[18] = run<18>(n[18], out, cyc); r[19] = run<19>(n[19], out, cyc); r[20] = run<20>(n[20], out, cyc); r[21] = run<21>(n[21], out, cyc);
-  r[22] = run<22>(n[22], out, cyc);
+  r[22] = run<22>(n[22], out, cyc); r[23] = run<23>(n[23], out, cyc); r[24] = run<24>(n[24], out, cyc); r[25] = run<25>(n[25], out, cyc);
   printf("\nrelative to v_fma_f64 (one wave per SIMD, 4 waves per CU, 8 independent chains):\n");
-  for (int i = 1; i < 23; ++i) printf("  %-26s %.2f\n", n[i], r[i] / f);
+  for (int i = 1; i < 26; ++i) printf("  %-26s %.2f\n", n[i], r[i] / f);
   return 0;
 }
