@@ -234,7 +234,7 @@ def main():
         b_, n_, S0, Qb = c3_reach_parameters(first, B)
         hn = normal_depth_rect(b_, n_, S0, Qb)
         L = (N - 1) * dx
-        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="rect_uniform", device=local)
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="rect_uniform", device=local, monitor=False)
         batch.set_scheme(theta, dt, dx, tol, 100)
         batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
         batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
@@ -252,7 +252,7 @@ def main():
         rng = np.random.default_rng(20260215)
         n_members = (0.020 + 0.040 * rng.random(first + B))[first:]
         theta, dt, dx, tol = solver.theta, float(solver.time_step), solver.spatial_step, 1e-6
-        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="table", device=local)
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="table", device=local, monitor=False)
         batch.set_scheme(theta, dt, dx, tol, 100)
         if args.per_reach_geometry:
             batch.set_geometry_table({k: np.broadcast_to(np.asarray(ch.node_geometry[k], dtype=np.float64), (B, N)) for k in A.GEO_ROWS},
@@ -291,7 +291,7 @@ def main():
         rng = np.random.default_rng(20260216)
         n_members = (0.025 + 0.015 * rng.random(first + B))[first:]
         theta, dt, dx, tol = 0.7, 300.0, solver.spatial_step, 1e-6
-        batch = PreissmannBatch(B, N, levels, dtype="f64", section_mode="irregular", device=local)
+        batch = PreissmannBatch(B, N, levels, dtype="f64", section_mode="irregular", device=local, monitor=False)
         batch.set_scheme(theta, dt, dx, tol, 100)
         batch.set_geometry_irregular(ch.node_geometry, n_main_override=n_members)
         batch.set_boundary(A.UPSTREAM, boundary_to_spec(us, levels, dt))
@@ -306,7 +306,7 @@ def main():
         b_, m_, n_, S0, Qb = c5_reach_parameters(first, B)
         hn = normal_depth_trap(b_, m_, n_, S0, Qb)
         L = (N - 1) * dx
-        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="trap_uniform", device=local)
+        batch = PreissmannBatch(B, N, levels, dtype=args.dtype, section_mode="trap_uniform", device=local, monitor=False)
         batch.set_scheme(theta, dt, dx, tol, 100)
         batch.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B), side_slope=m_)
         batch.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_RATING_POWER, dict(a=Qb / hn ** 1.6, b=np.full(B, 1.6),

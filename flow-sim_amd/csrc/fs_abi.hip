@@ -307,6 +307,8 @@ struct fs_batch {
   int poly_K = 0;
   size_t geo_reach_stride = 0, poly_reach_stride = 0;     // per-reach geometry (elements between the tables of two reaches), 0: shared
   int32_t *reach_nodes = nullptr;       // [B] per-reach node counts (heterogeneous batch) or nullptr
+  std::vector<int32_t> reach_nodes_host;      // its host copy (empty: every reach has n_nodes): where a reach's last node is
+  bool any_storage[2] = {false, false}; // some reach's boundary on this side is a storage kind (per-reach kinds: OR over the reaches)
   void *reach_scheme = nullptr;         // [3][B] per-reach theta, dt, dx or nullptr
   int32_t *reach_kinds = nullptr;       // [2][B] per-reach boundary kinds or nullptr
   bool kinds_per_reach[2] = {false, false};
@@ -432,6 +434,16 @@ __global__ void gather_boundary_iterate(const R *hg, const R *Qg, const int32_t 
   const size_t last = (reach_nodes ? (size_t)reach_nodes[r] : N) - 1;
   out[r] = (double)hg[r * N]; out[B + r] = (double)Qg[r * N];
   out[2 * B + r] = (double)hg[r * N + last]; out[3 * B + r] = (double)Qg[r * N + last];
+}
+
+// the downstream half of the level-0 hydrograph row from the state on the device: node reach_nodes[r] - 1 of every reach
+// (fs_batch_set_reach_nodes after fs_batch_set_state: the row was filled from column N - 1)
+template <typename R>
+__global__ void refresh_level0_downstream(const R *hk, const R *Qk, const int32_t *reach_nodes, R *hydro, size_t B, size_t N) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B) return;
+  const size_t last = (reach_nodes ? (size_t)reach_nodes[r] : N) - 1;
+  hydro[2 * B + r] = hk[r * N + last]; hydro[3 * B + r] = Qk[r * N + last];
 }
 
 // reaches whose open level still iterates (fs_batch_iterate): not yet accepted and not failed
@@ -748,6 +760,7 @@ static const char *pack_polylines(const double *table, const int32_t *n_pts, int
     lim[i] = limits[2 * i]; lim[N + i] = limits[2 * i + 1];
     const double node_const[5] = {table[(size_t)FS_GEO_N_LEFT * N + i], table[(size_t)FS_GEO_N_MAIN * N + i],
                                   table[(size_t)FS_GEO_N_RIGHT * N + i], table[(size_t)FS_GEO_CURVATURE * N + i], zmin};
+    if (!tz) continue;                 // no stage tables for this batch (set_irregular): the kernels walk the edges
     // the node's table, then into the device layout: breakpoints [N][KP], intervals [P][FS_PT_BLOCK / 2][N] pairs (fs_poly.hpp)
     const size_t KP = fs::poly_table_bp(max_pts);
     std::vector<double> blk(fs::poly_table_stride(max_pts));
@@ -771,13 +784,27 @@ static int set_irregular(fs_batch *b, const double *table, const int32_t *n_pts,
   FS_ON_DEVICE(b);
   const size_t N = b->d.n_nodes, P = max_pts, per = (size_t)fs::FS_GEOX_NROWS * N;
   std::vector<double> xt(n_sets * P * N, 0.0), zt(n_sets * P * N, 0.0), lim(n_sets * 2 * N, 0.0), tabs(n_sets * per);
+  // Stage tables: poly_table_stride(P) numbers per node (about 10 KB at 40 stations) - times N, times one set per reach for
+  // per-reach channels.  Beyond a bound (FS_POLY_TABLE_MAX_BYTES, default 8 GiB: staged once on the host, then resident in HBM)
+  // the batch gets no tables and every evaluation walks its polyline's edges (fs_poly.hpp: poly_K = 0, the round-2 path - same
+  // results, about five times the instructions); FS_POLY_WALK=1 forces that path.  fs_batch_poly_tables() says which one it is.
   const size_t tstride = (size_t)fs::poly_table_stride(max_pts);
-  std::vector<double> tz(n_sets * N * tstride, std::numeric_limits<double>::infinity());
+  size_t table_cap = (size_t)8 << 30;
+  if (const char *env = std::getenv("FS_POLY_TABLE_MAX_BYTES")) table_cap = (size_t)std::strtoull(env, nullptr, 10);
+  const double table_bytes = (double)n_sets * (double)N * (double)tstride * sizeof(double);
+  const bool walk = std::getenv("FS_POLY_WALK") != nullptr || table_bytes > (double)table_cap;
+  std::vector<double> tz;
+  try {
+    if (!walk) tz.assign(n_sets * N * tstride, std::numeric_limits<double>::infinity());
+  } catch (const std::bad_alloc &) {
+    return fail("fs_batch_set_geometry_irregular: no host memory to stage " + std::to_string((size_t)(table_bytes / (1 << 20))) +
+                " MiB of stage tables (lower FS_POLY_TABLE_MAX_BYTES to fall back to the edge walk)");
+  }
   for (size_t r = 0; r < n_sets; ++r) {
     const double *tab_r = table + r * FS_GEO_NPARAM * N;
     if (const char *err = pack_polylines(tab_r, n_pts + r * N, max_pts, x + r * N * P, z + r * N * P, limits + r * 2 * N, N,
                                          xt.data() + r * P * N, zt.data() + r * P * N, lim.data() + r * 2 * N,
-                                         tz.data() + r * N * tstride))
+                                         walk ? nullptr : tz.data() + r * N * tstride))
       return fail(err);
     const std::vector<double> ext = extend_table(tab_r, N);
     std::memcpy(tabs.data() + r * per, ext.data(), per * sizeof(double));
@@ -786,8 +813,10 @@ static int set_irregular(fs_batch *b, const double *table, const int32_t *n_pts,
   for (void **q : old) if (*q) { (void)hipFree(*q); *q = nullptr; }
   if (b->poly_n) { (void)hipFree(b->poly_n); b->poly_n = nullptr; }
   b->poly_K = 0;
-  if (!std::getenv("FS_POLY_WALK")) {          // (FS_POLY_WALK=1: no stage tables, every evaluation walks the edges - the round-2 path, kept for comparison)
-    if (upload(b, &b->poly_tz, tz.data(), tz.size())) return -1;
+  if (!walk) {
+    if (upload(b, &b->poly_tz, tz.data(), tz.size()))
+      return fail("fs_batch_set_geometry_irregular: " + std::to_string((size_t)(table_bytes / (1 << 20))) + " MiB of stage tables do not fit the "
+                  "device (" + g_err + "); lower FS_POLY_TABLE_MAX_BYTES to fall back to the edge walk");
     b->poly_K = (int)P;
   }
   if (upload(b, &b->geo_table, tabs.data(), tabs.size()) || upload(b, &b->poly_x, xt.data(), xt.size()) ||
@@ -847,15 +876,32 @@ int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes) {
   if (!b) return fail("null handle");
   FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches;
+  // the level-0 hydrograph row holds each reach's LAST node (fs_batch_set_state): when the counts change under a state that is
+  // already on the device and has not been stepped, the row follows them
+  auto refresh_row0 = [&]() -> int {
+    if (!b->have_state || b->level != 0) return 0;
+    const dim3 grid((unsigned)((B + 255) / 256));
+    if (b->d.dtype == FS_F64)
+      hipLaunchKernelGGL((refresh_level0_downstream<double>), grid, dim3(256), 0, b->stream, (const double *)b->hk, (const double *)b->Qk,
+                         b->reach_nodes, (double *)b->hydro, B, (size_t)b->d.n_nodes);
+    else
+      hipLaunchKernelGGL((refresh_level0_downstream<float>), grid, dim3(256), 0, b->stream, (const float *)b->hk, (const float *)b->Qk,
+                         b->reach_nodes, (float *)b->hydro, B, (size_t)b->d.n_nodes);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+  };
   if (!n_nodes) {
     if (b->reach_nodes) { (void)hipFree(b->reach_nodes); b->reach_nodes = nullptr; }
-    return 0;
+    b->reach_nodes_host.clear();
+    return refresh_row0();
   }
   for (size_t r = 0; r < B; ++r)
     if (n_nodes[r] < 2 || n_nodes[r] > b->d.n_nodes) return fail("fs_batch_set_reach_nodes: every reach needs 2 <= nodes <= n_nodes of the batch");
   if (!b->reach_nodes) HIP_TRY(hipMalloc((void **)&b->reach_nodes, B * 4));
   HIP_TRY(hipMemcpy(b->reach_nodes, n_nodes, B * 4, hipMemcpyHostToDevice));
-  return 0;
+  b->reach_nodes_host.assign(n_nodes, n_nodes + B);
+  return refresh_row0();
 }
 
 int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx) {
@@ -904,6 +950,8 @@ int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, c
     HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)other * B, same.data(), B * 4, hipMemcpyHostToDevice));
   }
   b->bc_kind[side] = kinds[0]; b->bc_stride[side] = 1; b->kinds_per_reach[side] = true;
+  b->any_storage[side] = false;
+  for (size_t r = 0; r < B; ++r) b->any_storage[side] = b->any_storage[side] || fs::bc_is_storage(kinds[r]);
   b->have_bc[side] = true;
   return 0;
 }
@@ -928,7 +976,7 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
       HIP_TRY(hipMemsetAsync(b->bc_params[side], 0, 3 * B * b->esz, b->stream));
     }
     b->bc_kind[side] = kind; b->bc_stride[side] = 1; b->have_bc[side] = true;
-    b->kinds_per_reach[side] = false;
+    b->kinds_per_reach[side] = false; b->any_storage[side] = false;
     if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
       std::vector<int32_t> same(B, kind);
       HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
@@ -957,7 +1005,7 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
   if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
   b->bc_kind[side] = kind; b->bc_stride[side] = per_reach ? 1 : 0;
   b->have_bc[side] = true;
-  b->kinds_per_reach[side] = false;
+  b->kinds_per_reach[side] = false; b->any_storage[side] = fs::bc_is_storage(kind);
   if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
     std::vector<int32_t> same(B, kind);
     HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
@@ -979,8 +1027,9 @@ int fs_batch_set_state(fs_batch *b, const double *h, const double *Q) {
   }
   std::vector<double> row(4 * B);
   for (size_t r = 0; r < B; ++r) {
+    const size_t last = (b->reach_nodes_host.empty() ? N : (size_t)b->reach_nodes_host[r]) - 1;     // the reach's own last node, not the caller's padding
     row[0 * B + r] = h[r * N]; row[1 * B + r] = Q[r * N];
-    row[2 * B + r] = h[r * N + N - 1]; row[3 * B + r] = Q[r * N + N - 1];
+    row[2 * B + r] = h[r * N + last]; row[3 * B + r] = Q[r * N + last];
   }
   void *p = b->hydro;
   if (upload(b, &p, row.data(), 4 * B)) return -1;
@@ -1107,7 +1156,7 @@ int fs_batch_restart(fs_batch *b, int32_t level, const double *h, const double *
                      const double *storage_stage) {
   if (!b || !h || !Q || !h_guess || !Q_guess) return fail("fs_batch_restart: null argument");
   if (level < 0 || level + 1 >= b->d.max_levels) return fail("fs_batch_restart: level out of range");
-  if (level > 0 && !storage_stage && b->have_bc[FS_DOWNSTREAM] && fs::bc_is_storage(b->bc_kind[FS_DOWNSTREAM]))
+  if (level > 0 && !storage_stage && b->have_bc[FS_DOWNSTREAM] && b->any_storage[FS_DOWNSTREAM])      // (per-reach kinds: any reach)
     return fail("fs_batch_restart: a storage boundary continues from the reservoir stage of `level` (storage_stage[B], "
                 "fs_batch_get_storage_stage); without it the run would go on from stage 0");
   if (fs_batch_set_state(b, h, Q)) return -1;
@@ -1242,7 +1291,7 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
                              (const double *)b->poly_x, (const double *)b->poly_z, b->poly_n,
                              (int64_t)b->geo_reach_stride, (int64_t)b->poly_reach_stride,
                              (double *)dev[0], (double *)dev[1], (double *)dev[2], (double *)dev[3], (double *)dev[4],
-                             (double *)dev[5], (double *)dev[6], (double *)dev[7]};
+                             (double *)dev[5], (double *)dev[6], (double *)dev[7], b->reach_nodes};
     hipLaunchKernelGGL((fs::derive_fields_kernel<double, 2>), grid, dim3(256), 0, b->stream, a);
   } else {
     fs::DeriveArgs<float> a{b->d.n_reaches, b->d.n_nodes, first, n, b->d.section_mode, (const float *)b->hist_h,
@@ -1250,7 +1299,7 @@ int fs_batch_derive_device(fs_batch *b, int32_t first, int32_t n, int32_t fields
                             (const float *)b->poly_x, (const float *)b->poly_z, b->poly_n,
                             (int64_t)b->geo_reach_stride, (int64_t)b->poly_reach_stride,
                             (float *)dev[0], (float *)dev[1], (float *)dev[2], (float *)dev[3], (float *)dev[4],
-                            (float *)dev[5], (float *)dev[6], (float *)dev[7]};
+                            (float *)dev[5], (float *)dev[6], (float *)dev[7], b->reach_nodes};
     hipLaunchKernelGGL((fs::derive_fields_kernel<float, 4>), grid, dim3(256), 0, b->stream, a);
   }
   HIP_TRY(hipGetLastError());
@@ -1310,6 +1359,8 @@ int fs_kernel_table_entry(int32_t i, int32_t *out) {
 }
 
 int32_t fs_batch_kernel_index(fs_batch *b) { return (b && b->kern) ? (int32_t)(b->kern - kEntries) : -1; }
+
+int32_t fs_batch_poly_tables(fs_batch *b) { return (b && b->poly_x) ? (b->poly_K > 0 ? 1 : 0) : -1; }
 
 int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_per_reach, int32_t *lds_bytes,
                          int32_t *vgprs) {

@@ -1305,6 +1305,7 @@ template <typename R> struct DeriveArgs {
   const int32_t *poly_n;
   int64_t geo_reach_stride, poly_reach_stride;      // per-reach tables (see KernelArgs), 0: shared
   R *level, *area, *top, *froude, *vel, *cel, *amp, *peak;   // [n][B][N] (peak: [B][N]) or nullptr
+  const int32_t *reach_nodes;     // [B] or nullptr: nodes of each reach of a ragged batch (fs_batch_set_reach_nodes); entries beyond come out 0
 };
 
 template <typename R, int V> struct Pack { typedef R type __attribute__((ext_vector_type(V))); };
@@ -1340,10 +1341,13 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
   const bool whole = cnt == V && BN % V == 0;        // every level's row of this thread starts on a 16-byte boundary
   SecParams<R> s[V];
   PolyNode<R> pnode[V];
+  bool beyond[V];                            // ragged batches: a slot past the reach's own node count (no history there: results 0)
 #pragma unroll
   for (int e = 0; e < V; ++e) {
     const size_t i = i0 + (e < cnt ? e : 0);
     const int reach = (int)(i / a.N), node = (int)(i - (size_t)reach * a.N);
+    const int nodes_r = a.reach_nodes ? a.reach_nodes[reach] : a.N;        // the step kernels' Geometry::init(a, reach, n_nodes)
+    beyond[e] = node >= nodes_r;
     pnode[e].n = 0;
     if (a.section_mode == FS_SEC_TABLE || a.section_mode == FS_SEC_IRREGULAR) {
       auto g = [&](int row) { return a.geo_table[(size_t)reach * a.geo_reach_stride + (size_t)row * a.N + node]; };
@@ -1359,7 +1363,7 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
       }
     } else {
       const R z_us = a.geo_uniform[(size_t)FS_RU_Z_US * a.B + reach], z_ds = a.geo_uniform[(size_t)FS_RU_Z_DS * a.B + reach];
-      const R w2 = R(node) / R(a.N - 1);
+      const R w2 = R(node) * (R(1) / R(nodes_r - 1));       // the reach's own node count, as Geometry<R, *_UNIFORM>::bed
       s[e].z = z_us * (R(1) - w2) + z_ds * w2;
       s[e].b = a.geo_uniform[(size_t)FS_RU_WIDTH * a.B + reach];
       s[e].m = a.section_mode == FS_SEC_TRAP_UNIFORM ? a.geo_uniform[(size_t)FS_TU_SIDE_SLOPE * a.B + reach] : R(0);
@@ -1377,6 +1381,7 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
     load_pack<R, V>(a.hist_Q + src, whole, cnt, Q);
 #pragma unroll
     for (int e = 0; e < V; ++e) {
+      if (beyond[e]) { h[e] = R(1); Q[e] = R(0); }        // (never written by the step kernel)
       // area and top width: cross_section.py:623-679 (incl. the over-bank convention)
       const SecParams<R> &se = s[e];
       const R d = fmax_(R(0), h[e]);
@@ -1398,6 +1403,7 @@ template <typename R, int V> __global__ __launch_bounds__(256) void derive_field
       cel[e] = Ve + sqrt_(R(kG) * Ae / Te);
       am[e] = h[e] - h0[e];
       peak[e] = fmax_(peak[e], am[e]);
+      if (beyond[e]) { lev[e] = A[e] = T[e] = Fr[e] = vel[e] = cel[e] = am[e] = R(0); peak[e] = R(0); }
     }
     if (a.level) store_pack<R, V>(a.level + dst, whole, cnt, lev);
     if (a.area) store_pack<R, V>(a.area + dst, whole, cnt, A);

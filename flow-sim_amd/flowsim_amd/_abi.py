@@ -87,6 +87,7 @@ SIGNATURES = {
     "fs_kernel_table_size": (C.c_int32, []),
     "fs_kernel_table_entry": (C.c_int, [C.c_int32, _I]),
     "fs_batch_kernel_index": (C.c_int32, [_P]),
+    "fs_batch_poly_tables": (C.c_int32, [_P]),
 }
 
 _lib = None

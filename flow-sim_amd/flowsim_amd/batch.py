@@ -43,7 +43,10 @@ def _dptr(a):
 class PreissmannBatch:
     def __init__(self, n_reaches: int, n_nodes: int, max_levels: int, dtype: str = "f64",
                  section_mode: str = "rect_uniform", device: int = 0, history: bool = False, trace: bool = False,
-                 monitor: bool = False):
+                 monitor: bool = True):
+        """monitor: the conditioning monitor of the on-chip elimination (status ILL_CONDITIONED, the stand-in for the reference's
+        `diagnos` check, preissmann.py:133-144) runs on every batch unless the caller opts out - a batch without history or
+        trace then runs the step kernels compiled without diagnostics (1 - 3 % faster on the benchmark shapes; bench.py does)."""
         self.B, self.N, self.L = int(n_reaches), int(n_nodes), int(max_levels)
         self.dtype = {"f64": A.F64, "f32": A.F32}[dtype]
         self.mode = {"rect_uniform": A.SEC_RECT_UNIFORM, "trap_uniform": A.SEC_TRAP_UNIFORM,

@@ -8,7 +8,7 @@ from .batch import PreissmannBatch
 from .hydromodel.preissmann import boundary_to_spec
 
 
-def run_manning_ensemble(solver, n_main_values, tolerance=1e-4, max_iter=100, dtype="f64", device=0):
+def run_manning_ensemble(solver, n_main_values, tolerance=1e-4, max_iter=100, dtype="f64", device=0, monitor=True):
     """`solver`: a set-up (not yet run) PreissmannSolver whose channel provides geometry, boundaries
     and initial conditions; the initial conditions are shared by all members (the reference's
     members start from the same downstream level and the same flow; their GVF profiles differ
@@ -19,7 +19,7 @@ def run_manning_ensemble(solver, n_main_values, tolerance=1e-4, max_iter=100, dt
     n_vals = np.ascontiguousarray(n_main_values, dtype=np.float64)
     B, N, nt = len(n_vals), solver.number_of_nodes, solver.number_of_time_levels
     ics = getattr(ch, "member_ics", None)
-    with PreissmannBatch(B, N, max(nt, 2), dtype=dtype, section_mode="table", device=device) as b:
+    with PreissmannBatch(B, N, max(nt, 2), dtype=dtype, section_mode="table", device=device, monitor=monitor) as b:
         b.set_scheme(solver.theta, solver.time_step, solver.spatial_step, tolerance, max_iter)
         b.set_geometry_table(ch.node_geometry, n_main_override=n_vals)
         b.set_boundary(A.UPSTREAM, boundary_to_spec(ch.upstream_boundary, max(nt, 2), solver.time_step))

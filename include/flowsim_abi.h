@@ -130,7 +130,10 @@ enum {
                            step kernels compiled without those stores */
   FS_FLAG_TRACE = 2,    /* keep ||R|| of every Newton iteration (what run(verbose=3) prints, preissmann.py:149-152) */
   FS_FLAG_MONITOR = 4   /* run the conditioning monitor (FS_ILL_CONDITIONED) also on a batch that keeps neither history nor trace:
-                           selects the kernels compiled with diagnostics (about 1 % slower on the 4 096-node benchmark shape) */
+                           selects the kernels compiled with diagnostics (measured: 1.2 % slower on the 4 096-node benchmark shape, 3 % on
+                           the 121-node ensemble).  The Python binding sets it by default (PreissmannBatch(monitor=True), the reference's
+                           per-run `diagnos` check stands behind it, preissmann.py:133-144); a caller that wants the fastest kernels and
+                           knows its flow to be subcritical passes monitor=False, as bench.py does. */
 };
 #define FS_TRACE_CAP 64 /* iterations per level kept by FS_FLAG_TRACE */
 
@@ -302,6 +305,11 @@ int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_
 int32_t fs_kernel_table_size(void);
 int fs_kernel_table_entry(int32_t i, int32_t *out);
 int32_t fs_batch_kernel_index(fs_batch *b);
+/* FS_SEC_IRREGULAR: 1 when the batch evaluates its polylines from stage tables, 0 when it walks their edges (the same results at
+ * about five times the instructions): the tables take about 10 KB per node at 40 stations, per channel, and
+ * fs_batch_set_geometry_irregular(_per_reach) leaves them out beyond FS_POLY_TABLE_MAX_BYTES (environment, default 8 GiB) or with
+ * FS_POLY_WALK=1.  The reference evaluates every call by walking the polyline (cross_section.py:248-538). -1: no polylines set. */
+int32_t fs_batch_poly_tables(fs_batch *b);
 
 #ifdef __cplusplus
 }

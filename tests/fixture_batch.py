@@ -70,8 +70,10 @@ def is_rect_uniform(p: O.Problem):
             and flat(g["b_main"]) and flat(g["n_main"]))
 
 
-def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main_override=None):
-    """One batch from a list of oracle Problems that share N, nt and the scheme parameters."""
+def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main_override=None, monitor=None):
+    """One batch from a list of oracle Problems that share N, nt and the scheme parameters.  monitor=None: as the history flag (a
+    test that leaves the history out wants the step kernels compiled without diagnostics, the bench shapes)."""
+    monitor = history if monitor is None else monitor
     p0 = problems[0]
     B = len(problems)
     if mode == "auto":
@@ -82,7 +84,7 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
         if mode != "rect_uniform" and B > 1:
             assert all(all(np.array_equal(p.geo[k], p0.geo[k]) for k in O.GEO_KEYS) for p in problems), \
                 "TABLE geometry is shared by the batch: reaches with their own channel need their own batch"
-    b = PreissmannBatch(B, p0.N, p0.nt, dtype=dtype, section_mode=mode, history=history)
+    b = PreissmannBatch(B, p0.N, p0.nt, dtype=dtype, section_mode=mode, history=history, monitor=monitor)
     b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
     if mode == "rect_uniform":
         b.set_geometry_uniform([p.geo["b_main"][0] for p in problems], [p.geo["n_main"][0] for p in problems],
@@ -101,7 +103,7 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
     return b
 
 
-def hetero_batch_from_problems(problems, mode="table", history=True):
+def hetero_batch_from_problems(problems, mode="table", history=True, monitor=None):
     """ONE batch from oracle Problems that share nothing but the tolerance: every reach its own channel (node table), node
     count, theta / dt / dx, boundary kinds and number of levels (fs_batch_set_geometry_table_per_reach, fs_batch_set_reach_nodes,
     fs_batch_set_reach_scheme, fs_batch_set_bc_per_reach).  Rows of shorter reaches are padded with their last node."""
@@ -112,7 +114,7 @@ def hetero_batch_from_problems(problems, mode="table", history=True):
     def pad(a):
         a = np.asarray(a, dtype=np.float64)
         return np.concatenate([a, np.full(N - len(a), a[-1])])
-    b = PreissmannBatch(B, N, L, section_mode=mode, history=history)
+    b = PreissmannBatch(B, N, L, section_mode=mode, history=history, monitor=history if monitor is None else monitor)
     b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
     b.set_geometry_table({k: np.stack([pad(p.geo[k]) for p in problems]) for k in A.GEO_ROWS})
     b.set_reach_nodes([p.N for p in problems])

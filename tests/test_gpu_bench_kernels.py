@@ -54,7 +54,7 @@ def test_c3_flagship_kernel_at_4096_nodes_against_the_reference():
     assert rel_err(hn, fx["initial_conditions"][:, 0, 0], 1e-3) <= 1e-10
     L = (N - 1) * meta["dx"]
     for uniform_ic in (True, False):
-        with PreissmannBatch(B, N, nt, section_mode="rect_uniform") as b:      # history=False, trace=False: as bench.py
+        with PreissmannBatch(B, N, nt, section_mode="rect_uniform", monitor=False) as b:      # history=False, trace=False, no monitor: as bench.py
             b.set_scheme(meta["theta"], meta["dt"], meta["dx"], meta["tolerance"], 100)
             b.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
             b.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, nt, meta["dt"])))
@@ -91,7 +91,7 @@ def test_c5_kernel_at_512_nodes_against_the_reference(dtype):
     hn = normal_depth_trap(b_, m_, n_, S0, Qb)
     assert rel_err(hn, fx["params"][:, 5], 1e-3) <= 1e-10
     L = (N - 1) * meta["dx"]
-    with PreissmannBatch(B, N, nt, dtype=dtype, section_mode="trap_uniform") as b:
+    with PreissmannBatch(B, N, nt, dtype=dtype, section_mode="trap_uniform", monitor=False) as b:
         b.set_scheme(meta["theta"], meta["dt"], meta["dx"], 1e-6 if dtype == "f64" else 1e-3, 100)
         b.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B), side_slope=m_)
         b.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, nt, meta["dt"])))

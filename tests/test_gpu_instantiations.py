@@ -210,6 +210,79 @@ def test_instantiation_against_the_oracle(e, monkeypatch):
         assert np.array_equal(its, ref["iters"])
 
 
+# ---- a SECOND recipe for the entries whose node evaluation is the intricate one (tables, polylines) ----
+# Round 3's (8, 1) polyline kernel was right or wrong depending on code the case never executed: one case per entry is a thin net
+# for a miscompile.  The second case comes from the reference's own random sweep (tests/golden/random_sweep.npz: the reference
+# built these channels and ran them; compared here with ITS histories, not an oracle's): other sections, other boundary kinds,
+# other node counts than the first recipe's.
+SWEEP = {i: (fx, m) for i, fx, m in O.sweep_cases(os.path.join(GOLDEN, "random_sweep.npz"))}
+SECOND_POLY = {-1: [58, 50, 52, 55], 0: [50, 52, 53, 58, 55, 48], 2: [54, 57]}           # by boundary class (2: flow upstream, normal depth downstream)
+SECOND_TABLE = {-1: [61, 62, 65, 70, 68, 60], 0: [78, 79, 8, 10, 24, 3, 75, 21, 12]}      # general storages; compound sections, bends
+
+
+def second_case_for(e):
+    """(problem, mode, reference arrays or None) - None: compare with the oracle"""
+    from flowsim_amd import _abi as A
+    sec, bck = e["section_mode"], e["boundary_class"]
+    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"] * (64 // e["waves_per_reach"] if e.get("long_reach") else 1)
+    if sec == A.SEC_TABLE and e.get("long_reach"):
+        pair = GENERAL_PAIRS[(e["index"] + 4) % len(GENERAL_PAIRS)]
+        return prismatic_problem(e, pair, e["index"] % 2 == 1, n_steps=3), "table", None
+    if sec == A.SEC_TABLE and bck >= 2:
+        return fixture_problem("gerd_ensemble", 5, member=e["index"] % 8), "table", None
+    pool = (SECOND_TABLE if sec == A.SEC_TABLE else SECOND_POLY)[min(bck, 2)]
+    fits = [i for i in pool if SWEEP[i][1]["N"] <= cap]
+    i = fits[e["index"] % len(fits)]
+    fx, m = SWEEP[i]
+    return O.problem_from_fixture(fx, m), ("table" if sec == A.SEC_TABLE else "irregular"), (fx, m)
+
+
+SECOND = [e for e in TABLE if e["section_mode"] in (2, 3)]
+
+
+@pytest.mark.parametrize("e", SECOND, ids=[_id(e) for e in SECOND])
+def test_table_and_polyline_instantiations_on_a_second_case(e, monkeypatch):
+    from fixture_batch import batch_from_problems
+    from flowsim_amd import _abi as A
+    p, mode, ref_fx = second_case_for(e)
+    f32 = e["dtype"] == A.F32
+    if f32:
+        p.tol = max(p.tol, 1e-3)
+    if ref_fx is None:
+        ref = oracle_run(p)
+        assert ref["status"] == 0
+        d, f, ref_its = ref["depth"], ref["flow"], ref["iters"]
+        hfloor, qfloor = 1e-3, 1.0
+    else:
+        fx, m = ref_fx
+        d, f, ref_its = fx["depth"], fx["flow"], fx["iters"]
+        hfloor, qfloor = 1e-3 * m["h_n"], 1e-3 * m["Qb"]
+    monkeypatch.setenv("FS_KERNEL_INDEX", str(e["index"]))
+    history = bool(e["diag"])
+    with batch_from_problems([p], mode=mode, dtype="f32" if f32 else "f64", history=history) as b:
+        b.step(p.nt - 1)
+        assert b.kernel_index() == e["index"]
+        assert np.all(b.status() == 0), b.status()
+        hyd = b.hydrographs(0, p.nt)[:, :, 0]
+        its = b.iterations(0, p.nt)[:, 0]
+        hist = b.history_arrays(0, p.nt) if history else None
+    tol = TOL_F32 if f32 else TOL
+    assert rel_err(hyd[:, 0], d[:, 0], hfloor) <= tol and rel_err(hyd[:, 2], d[:, -1], hfloor) <= tol
+    assert rel_err(hyd[:, 1], f[:, 0], qfloor) <= tol and rel_err(hyd[:, 3], f[:, -1], qfloor) <= tol
+    if hist is not None:
+        assert rel_err(hist[0][:, 0], d, hfloor) <= tol and rel_err(hist[1][:, 0], f, qfloor) <= tol
+    if not f32:
+        assert np.array_equal(its, ref_its)
+
+
+def test_the_second_recipes_differ_from_the_first():
+    assert len(SECOND) >= 30
+    for e in SECOND:
+        p1, _, _ = case_for(e)
+        p2, _, _ = second_case_for(e)
+        assert (p1.N, p1.dt, p1.ds.kind, p1.us.kind) != (p2.N, p2.dt, p2.ds.kind, p2.us.kind) or not np.array_equal(p1.geo["n_main"], p2.geo["n_main"]), _id(e)
+
+
 def test_the_table_is_what_this_file_expects():
     """every entry has a recipe, the recipes between them reach every boundary kind on both ends, and the forced index
     is refused when it does not fit"""

@@ -158,6 +158,7 @@ _solved_table = []
 _flagged = []          # (sweep, seed, Froude number or None, error) of every draw the conditioning monitor flagged
 _unflagged_froude = []
 ILL = 4                # FS_ILL_CONDITIONED
+FLAGGED_TOL = 1e-2     # a flagged draw may miss 1e-8, not the flood wave (tests/test_near_critical.py: the same bound against the reference)
 N_TABLE = int(os.environ.get("FS_SWEEP_TABLE", 128))
 
 
@@ -180,7 +181,10 @@ def test_random_compound_channel_against_the_oracle(seed):
     d, f = ref["depth"], ref["flow"]
     eh, eq = rel_err(h[:, 0], d, 1e-3 * info["hn"]), rel_err(Q[:, 0], f, 1e-3 * info["Qb"])
     if st == ILL:
+        # flagged is not a free pass: the kernel says 1e-8 is not promised, the flood wave must still be the same one (the bound
+        # tests/test_near_critical.py holds flagged reaches to against the reference itself)
         _flagged.append(("table", seed, None, max(eh, eq)))
+        assert eh <= FLAGGED_TOL and eq <= FLAGGED_TOL, ("flagged draw off by more than 1e-2", eh, eq, info)
     else:
         assert eh <= TOL and eq <= TOL, (eh, eq, info)
         assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
@@ -210,6 +214,7 @@ def test_random_reach_against_the_oracle(seed):
     if st == ILL:
         # the kernel itself says that this reach is beyond what its unpivoted elimination (or any solver, at 1e-8) stands for
         _flagged.append(("prismatic", seed, info["froude"], max(eh, eq)))
+        assert eh <= FLAGGED_TOL and eq <= FLAGGED_TOL, ("flagged draw off by more than 1e-2", eh, eq, info)
         return
     _unflagged_froude.append(info["froude"])
     assert eh <= TOL and eq <= TOL, (eh, eq, info)
@@ -223,6 +228,10 @@ def test_the_monitor_flags_few_draws_and_no_subcritical_prismatic_one():
     assert all(fr >= 0.85 for _, _, fr, _ in prism), prism            # a flag on a prismatic reach means supercritical (or nearly) flow
     assert len(prism) <= 0.02 * N_CASES + 2 and len(_flagged) - len(prism) <= 0.03 * N_TABLE + 2, _flagged
     assert sum(fr >= 0.9 for fr in _unflagged_froude) >= 1 or N_CASES < 300        # supercritical draws that pass at 1e-8 unflagged exist too
+    # what the flagged draws deviate by (each was held to FLAGGED_TOL above): printed with -s / in the captured output of a failure
+    for sweep, seed, fr, err in sorted(_flagged, key=lambda f: -f[3]):
+        print(f"flagged: {sweep} seed {seed} Froude {fr if fr is None else round(fr, 3)} deviation from the pivoted oracle {err:.3e}")
+    assert all(err <= FLAGGED_TOL for *_, err in _flagged)
 
 
 def tidal_problem(seed):

@@ -7,7 +7,7 @@ from flowsim_amd import BoundarySpec, PreissmannBatch, _abi as A
 from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
 B, N, K = int(sys.argv[1]) if len(sys.argv) > 1 else 8192, int(sys.argv[2]) if len(sys.argv) > 2 else 4096, 8
 b_, n_, S0, Qb = c3_reach_parameters(0, B); hn = normal_depth_rect(b_, n_, S0, Qb); L = (N - 1) * 250.0
-bt = PreissmannBatch(B, N, K + 2, section_mode="rect_uniform")
+bt = PreissmannBatch(B, N, K + 2, section_mode="rect_uniform", monitor=False)
 bt.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); bt.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
 bt.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, K + 2, 600.0)))
 bt.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))

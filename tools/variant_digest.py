@@ -9,7 +9,7 @@ from flowsim_amd import BoundarySpec, PreissmannBatch, _abi as A
 from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
 B, N, K = 96, int(os.environ.get("FS_DIGEST_NODES", "4096")), 6
 b_, n_, S0, Qb = c3_reach_parameters(0, B); hn = normal_depth_rect(b_, n_, S0, Qb); L = (N - 1) * 250.0
-with PreissmannBatch(B, N, K + 1, section_mode="rect_uniform") as x:
+with PreissmannBatch(B, N, K + 1, section_mode="rect_uniform", monitor=False) as x:
     x.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); x.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
     x.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, K + 1, 600.0)))
     x.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
