@@ -143,7 +143,7 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   // rows of the scalar system: N - 1 cells + the downstream boundary row; a long-reach kernel makes up to 64 / W passes
   const long cap = 64L * e.W * e.M * (e.longk ? 64 / e.W : 1);
   if (cap < N) return false;
-  if (e.longk && (need_any || (e.bck == 0 && beyond0))) return false;      // no iteration budget there; class 0: closed-form kinds
+  if (e.longk && ((need_any && e.bck != -1) || (e.bck == 0 && beyond0))) return false;      // iteration budget / host rows: class -1 (tables, polylines)
   if (e.full && N != cap) return false;
   if (!e.diag && need_diag) return false;
   if (need_any && e.bck != -1) return false;

@@ -124,6 +124,17 @@
                          // (16 W live doubles).  Measured on 65 536 x 4 096 (profiles/round3/second_wave_per_simd.md): W = 8 (the (8, 8)
                          // shape, two waves per SIMD) 7.9e6 -> 9.8e6 (the per-thread fold spills at 256 registers); W = 4 (the flagship
                          // (16, 4) shape) 1.072e7 -> 1.058e7: with four segments the per-thread fold has the shorter dependent chain
+#ifndef FS_XWAVE_CONT
+#define FS_XWAVE_CONT 0      // 1: multi-wave kernels without the conditioning monitor (the no-diagnostics benchmark shapes) solve the W + 1
+#endif                       // unknowns of the cross-wave step (p of the first row, m of each wave's last row) as ONE small tridiagonal system by
+                             // forward and backward continuants - two independent chains of W + 1 fmas and one reciprocal - instead of folding the
+                             // W wave segments pairwise (two dependent merge levels, the root closure, two unfolding levels: four reciprocal
+                             // chains).  Built and measured in round 4 (profiles/round4/cross_wave_continuants.txt): the phase itself gets
+                             // shorter (1 330 -> 1 170 ticks of 15 500 in the stamped build), the shipped flagship does not get faster
+                             // (121.1 -> 122.2 ms; 121.0 with the top tree record no longer requested ahead of the barrier): off
+#ifndef FS_XWAVE_FENCE
+#define FS_XWAVE_FENCE 0     // scheduling fences around the cross-wave step (bit 0: before, bit 1: after)
+#endif
 #ifndef FS_TREE_REGS
 #define FS_TREE_REGS 0       // flagship shapes: the in-wave tree's records stay in registers (6 levels x 4 numbers, valid in the lane that survives
 #endif                       // its level) and come back on the way down by DPP broadcasts / readlanes instead of through LDS slots
@@ -937,6 +948,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       }
 
       // ================= 4. across waves: fold, close with the upstream row, unfold =================
+#if FS_XWAVE_FENCE & 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       R tot = R(0);
       R pL, mR;                        // p of this wave's first row, m of its last one
       R mAw = R(0), mBw = R(0);        // m of this wave's first row / of the next wave's first row (shared nodes, below)
@@ -1000,6 +1014,72 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         mBw = read_lane(max_, (ws + 1) & (W - 1));
         if (ws == W - 1) mBw = R(0);
         if constexpr (kMonitor) { if (__builtin_amdgcn_readlane(gx, W - 1) > growth_limit_bits<R>()) grow = true; }
+      } else if constexpr (FS_XWAVE_CONT && !kMonitor && sizeof(R) == 8 && W > 1) {
+        // The W wave segments and the upstream row as ONE tridiagonal system.  With the links p_a(w) = rc_{w-1} - x_{w-1} and every
+        // wave's up row  m_a(w) = ru_w - u1_w p_a(w) - u3_w x_w  substituted into the down rows, the unknowns y = (p_0, x_0 .. x_{W-1}),
+        // x_w = m of wave w's last row, satisfy
+        //   row U  :                 (aU - bU u1_0) p_0 - bU u3_0 x_0                          = rU - bU ru_0
+        //   row k  : -d1_k x_{k-1} + (d2_k + d3_k u1_{k+1}) x_k - d3_k u3_{k+1} x_{k+1}        = rd_k - d1_k rc_{k-1} - d3_k (ru_{k+1} - u1_{k+1} rc_k)
+        //            (k = 0: + d1_0 p_0 and no rc_{-1} term; k = W-1: nothing to its right)
+        // Forward continuants th_i = B_i th_{i-1} - A_i C_{i-1} th_{i-2} with right-hand sides rho_i = th_{i-1} R_i - A_i rho_{i-1},
+        // backward ones ph_i, sg_i alike; det = th_W and  y_i = (ph_{i+1} rho_i - C_i th_{i-1} sg_{i+1}) / det : two independent chains
+        // of W + 1 steps and ONE reciprocal where the pairwise fold below has four dependent reciprocal chains (two merge levels, the
+        // two of the root closure).  The rows are diagonally dominant wherever the elimination itself is sound (fs_device.hpp); the
+        // kernels that watch the conditioning (kMonitor) keep the fold, whose merged segments the monitor reads.
+        Seg<R> sw[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          const R *p = sm.xseg[parity][w];
+          sw[w].u1 = p[0]; sw[w].u3 = p[1]; sw[w].ru = p[2]; sw[w].d1 = p[3]; sw[w].d2 = p[4]; sw[w].d3 = p[5];
+          sw[w].rd = p[6]; sw[w].rc = p[7];
+          tot += sm.xnorm[parity][w];
+        }
+        constexpr int n = W;                         // unknowns y_0 .. y_n
+        const R aU = sm.xbc[parity][0], bU = sm.xbc[parity][1], rU = sm.xbc[parity][2];
+        R Ac[n + 1], Bc[n + 1], Cc[n + 1], Rc[n + 1], AC[n + 1];     // AC[i] = A_i C_{i-1}
+        Ac[0] = R(0); Bc[0] = fma_(-bU, sw[0].u1, aU); Cc[0] = -(bU * sw[0].u3); Rc[0] = fma_(-bU, sw[0].ru, rU); AC[0] = R(0);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          const int i = k + 1;
+          Ac[i] = k == 0 ? sw[0].d1 : -sw[k].d1;
+          const R rdk = k == 0 ? sw[0].rd : fma_(-sw[k].d1, sw[k - 1].rc, sw[k].rd);
+          if (k + 1 < W) {
+            Bc[i] = fma_(sw[k].d3, sw[k + 1].u1, sw[k].d2); Cc[i] = -(sw[k].d3 * sw[k + 1].u3);
+            Rc[i] = fma_(-sw[k].d3, fma_(-sw[k + 1].u1, sw[k].rc, sw[k + 1].ru), rdk);
+          } else {
+            Bc[i] = sw[k].d2; Cc[i] = R(0); Rc[i] = rdk;
+          }
+          AC[i] = Ac[i] * Cc[i - 1];
+        }
+        R th[n + 1], rho[n + 1], ph[n + 2], sg[n + 2];
+        th[0] = Bc[0]; rho[0] = Rc[0];
+        th[1] = fma_(Bc[1], th[0], -AC[1]); rho[1] = fma_(th[0], Rc[1], -(Ac[1] * rho[0]));
+#pragma unroll
+        for (int i = 2; i <= n; ++i) { th[i] = fma_(Bc[i], th[i - 1], -(AC[i] * th[i - 2])); rho[i] = fma_(th[i - 1], Rc[i], -(Ac[i] * rho[i - 1])); }
+        ph[n + 1] = R(1); sg[n + 1] = R(0);
+        ph[n] = Bc[n]; sg[n] = Rc[n];
+        ph[n - 1] = fma_(Bc[n - 1], ph[n], -AC[n]); sg[n - 1] = fma_(ph[n], Rc[n - 1], -(Cc[n - 1] * sg[n]));
+#pragma unroll
+        for (int i = n - 2; i >= 1; --i) { ph[i] = fma_(Bc[i], ph[i + 1], -(AC[i + 1] * ph[i + 2])); sg[i] = fma_(ph[i + 1], Rc[i], -(Cc[i] * sg[i + 1])); }
+        const R rdet = frcp(th[n]);
+        R y[n + 1];
+        y[0] = fma_(ph[1], rho[0], -(Cc[0] * sg[1])) * rdet;
+#pragma unroll
+        for (int i = 1; i < n; ++i) y[i] = fma_(ph[i + 1], rho[i], -(Cc[i] * th[i - 1] * sg[i + 1])) * rdet;
+        y[n] = rho[n] * rdet;
+        R pw[W], ma[W + 1];
+        pw[0] = y[0];
+#pragma unroll
+        for (int w = 1; w < W; ++w) pw[w] = sw[w - 1].rc - y[w];
+        // m of every wave's first row from its own up row: the node there is shared with the wave before, and both
+        // copies must move by the same bits
+#pragma unroll
+        for (int w = 0; w < W; ++w) ma[w] = fma_(-sw[w].u1, pw[w], fma_(-sw[w].u3, y[w + 1], sw[w].ru));
+        ma[W] = R(0);
+        pL = pw[0]; mR = y[1]; mAw = ma[0]; mBw = ma[1];
+#pragma unroll
+        for (int w = 1; w < W; ++w)
+          if (wave == w) { pL = pw[w]; mR = y[w + 1]; mAw = ma[w]; mBw = ma[w + 1]; }
       } else {
       {
         // pairwise tree over the W wave segments (depth log2 W instead of a serial chain of W-1 merges;
@@ -1050,6 +1130,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           if (wave == w) { pL = pw[w]; mR = mw[w]; mAw = ma[w]; mBw = ma[w + 1]; }
       }
       }
+#if FS_XWAVE_FENCE & 2
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       FS_T(4);
       if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
       // ||R|| = sqrt(tot) (utility.py:20-22) is NaN or beyond the blow-up bound (preissmann.py:135-137) exactly when tot is

@@ -21,8 +21,11 @@
 //
 // Same arithmetic as the short kernel (same node terms, rows, merges), general form only: ragged node counts, boundary kinds
 // switched at run time (class 0 for the uniform section modes, -1 - incl. the general storage row - for tables and polylines),
-// diagnostics compiled in (history, residual trace, conditioning monitor).  No iteration budget: host-evaluated boundary rows
-// (fs_batch_iterate) stay with the short kernels.
+// diagnostics compiled in (history, residual trace, conditioning monitor).  The kernels of boundary class -1 (tables, polylines)
+// carry the iteration budget of fs_batch_iterate like their on-chip counterparts: a boundary that only the host can evaluate - a
+// RatingCurve subclass with moving gates, a Python callable as reservoir outlet (boundary.py:56-141; FS_BC_HOST_ROW) - runs on a
+// reach of any length, one Newton iteration per launch.  Nothing has to be carried across launches here: the Newton vector lives
+// in hg / Qg anyway, the level constants are rebuilt from hk / Qk (untouched while a level is open) at every launch.
 #pragma once
 
 namespace fs {
@@ -63,6 +66,13 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
 
   const int reach = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // fs_batch_iterate (boundary class -1): the iterations already spent on the open level, -1 once this reach has closed it
+  constexpr bool kBudget = (BCK == -1);
+  int it_entry = 0;
+  if (kBudget && a.iter_budget > 0) {
+    it_entry = a.it_done[reach];
+    if (it_entry < 0) return;                 // (whole workgroup)
+  }
   const int NS = a.N;
   const int N = a.reach_nodes ? a.reach_nodes[reach] : a.N, NC = N - 1;
   const int P = a.passes;                                     // P C >= N rows, P W <= 64 segments
@@ -221,10 +231,12 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
     const int level = a.level0 + step + 1;
     if (usd.target) usd.tgt = usd.target[(size_t)level * a.B + reach];
     if (dsd.target) dsd.tgt = dsd.target[(size_t)level * a.B + reach];
-    int it = 0;
+    int it = kBudget ? it_entry : 0;
+    int budget = (kBudget && a.iter_budget > 0) ? a.iter_budget : 0x7fffffff;
     bool converged = false;
     R Ynew = Yprev;
     while (!converged && status == FS_OK) {
+      if (kBudget && budget-- <= 0) break;
       ++it;
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }
       R nrm2 = R(0);
@@ -540,6 +552,10 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
       __syncthreads();                              // this iteration's stores before the next iteration's loads
     }
     if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
+    if (kBudget && a.iter_budget > 0) {
+      if (t == 0) a.it_done[reach] = (converged || status != FS_OK) ? -1 : it;
+      if (!converged) break;                  // budget spent: the Newton vector is in hg / Qg already
+    }
   }
   if (t == 0) a.status[reach] = (status == FS_OK && warn) ? (int)FS_ILL_CONDITIONED : status;
   if (ds_storage && t == tD) a.Yprev[reach] = Yprev;

@@ -326,6 +326,10 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_kernel_info(self._h, *[C.byref(x) for x in v]), "kernel_info")
         return dict(cells_per_thread=v[0].value, waves_per_reach=v[1].value, lds_bytes=v[2].value, vgprs=v[3].value)
 
+    def poly_tables(self):
+        """polyline batches: 1 = stage tables, 0 = edge walk (tables beyond FS_POLY_TABLE_MAX_BYTES or FS_POLY_WALK=1), -1 = none set"""
+        return self._lib.fs_batch_poly_tables(self._h)
+
     def kernel_index(self):
         """index into _abi.kernel_table() of the instantiation the last step / iterate launched"""
         return self._lib.fs_batch_kernel_index(self._h)

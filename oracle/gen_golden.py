@@ -777,7 +777,7 @@ def case_gerd_full():
 GATES_INFLOW_SCALE, GATES_STEPS = 8.0, 40
 
 
-def case_gerd_gates():
+def case_gerd_gates(name="gerd_gates", steps=None, spatial_step=None):
     """A boundary plugin with NO device form: RoseiresRatingCurve(smooth=False) (roseires_rating_curve.py:65-78, :111-140) -
     the gates open / close on the stage of the previous evaluation with a cool-down in simulation time, so discharge() is
     stateful and time-dependent.  The flood wave is the case's inflow table scaled by 8 above its base flow so that the
@@ -792,7 +792,8 @@ def case_gerd_gates():
     tab[:, 1] = tab[0, 1] + GATES_INFLOW_SCALE * (tab[:, 1] - tab[0, 1])
     inflow = Hydrograph(table=tab)
     rel = gd.GerdHydrograph()
-    rel.build(inflow_hydrograph=inflow, time_step=S.time_step, duration=GATES_STEPS * 3600, initial_stage=S.initial_gerd_level)
+    steps = GATES_STEPS if steps is None else steps
+    rel.build(inflow_hydrograph=inflow, time_step=S.time_step, duration=steps * 3600, initial_stage=S.initial_gerd_level)
     Q0 = rel.get_at(time=0)
     chs, secs = cf.load_trapzoid_xs(file_path=S.cross_sections_path, n_fp=None, n_main=None)
     bed = secs[-1].z_min
@@ -804,15 +805,25 @@ def case_gerd_gates():
     c = cf.import_table(S.coords_path, sort_by='chainage')
     ch.set_coords(coords=c[:, 1:], chainages=c[:, 0])
     ch.set_cross_sections(chainages=chs, sections=secs)
-    sol = PreissmannSolver(channel=ch, theta=S.theta, time_step=S.time_step, spatial_step=S.spatial_step,
-                           simulation_time=GATES_STEPS * 3600)
+    sol = PreissmannSolver(channel=ch, theta=S.theta, time_step=S.time_step, spatial_step=S.spatial_step if spatial_step is None else spatial_step,
+                           simulation_time=steps * 3600)
     out, wall = run_and_capture(sol, S.tolerance, slim=True)
     out["us_target"] = np.array(rel.table[:sol.number_of_time_levels, 1], dtype=np.float64)
     spec = rating_spec(rc, rr)
     spec.update(smooth=False, max_cooldown=float(rc.max_cooldown))
-    save("gerd_gates", out, base_meta(sol, S.tolerance, wall, rating=spec, inflow_scale=GATES_INFLOW_SCALE,
-                                      ds_initial_depth=float(ds.initial_depth), host_evaluated="downstream"))
+    save(name, out, base_meta(sol, S.tolerance, wall, rating=spec, inflow_scale=GATES_INFLOW_SCALE,
+                              ds_initial_depth=float(ds.initial_depth), host_evaluated="downstream"))
     os.chdir(os.path.dirname(os.path.abspath(__file__)))
+
+
+GATES_LONG_STEPS, GATES_LONG_DX = 30, 50.0
+
+
+def case_gerd_gates_long():
+    """The same plugin on a reach LONGER than a table kernel keeps on chip: cases/gerd_roseires at a spatial step of 50 m - 2 409
+    nodes (2 048 fit one lane grid) - under the same flood wave, 30 levels: the gates open at level 27 as they do at 1 000 m.
+    The reference has no node limit (solver.py:34-38, :53-55) and evaluates any RatingCurve subclass on any grid."""
+    case_gerd_gates("gerd_gates_long", GATES_LONG_STEPS, GATES_LONG_DX)
 
 
 def weir_outflow(stage):
@@ -978,7 +989,7 @@ CASES = {
     "result_summaries": case_result_summaries,
 }
 # long-running cases (minutes each): run with --only NAME
-SLOW_CASES = {"gerd_full": case_gerd_full, "gerd_gates": case_gerd_gates, "rmse_curve": case_rmse_curve}
+SLOW_CASES = {"gerd_full": case_gerd_full, "gerd_gates": case_gerd_gates, "rmse_curve": case_rmse_curve, "gerd_gates_long": case_gerd_gates_long}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -83,9 +83,48 @@ def merge(X, Y):
     return Z, dict(A1=A1, A2=A2, A3=A3, rc=X["rc"], det=det, scale=np.abs(X["d2"] * Y["u2"]) + np.abs(X["d3"] * Y["u1"]))
 
 
-def solve(data, R, m, T=None, dtype=np.float64, info=None):
+def continuant_close(seg, aU, bU, rU, dtype):
+    """The cross-wave step of the multi-wave kernels compiled without the conditioning monitor (fs_kernel.hpp, FS_XWAVE_CONT): the W
+    remaining segments and the upstream row as ONE tridiagonal system in y = (p_0, x_0 .. x_{W-1}), x_w = m of segment w's last row,
+    solved by forward and backward continuants with one reciprocal.  Returns (pL[W], mR[W]): the p of every segment's first row
+    and the m of its last one - what the way down starts from."""
+    W = len(seg["u1"])
+    n = W
+    g = lambda k, w: seg[k][w]
+    A, B, C, Rr, AC = (np.zeros(n + 1, dtype) for _ in range(5))
+    B[0] = aU - bU * g("u1", 0); C[0] = -(bU * g("u3", 0)); Rr[0] = rU - bU * g("ru", 0)
+    for k in range(W):
+        i = k + 1
+        A[i] = g("d1", 0) if k == 0 else -g("d1", k)
+        rdk = g("rd", 0) if k == 0 else g("rd", k) - g("d1", k) * g("rc", k - 1)
+        if k + 1 < W:
+            B[i] = g("d2", k) + g("d3", k) * g("u1", k + 1); C[i] = -(g("d3", k) * g("u3", k + 1))
+            Rr[i] = rdk - g("d3", k) * (g("ru", k + 1) - g("u1", k + 1) * g("rc", k))
+        else:
+            B[i] = g("d2", k); Rr[i] = rdk
+        AC[i] = A[i] * C[i - 1]
+    th, rho, ph, sg = np.zeros(n + 1, dtype), np.zeros(n + 1, dtype), np.zeros(n + 2, dtype), np.zeros(n + 2, dtype)
+    th[0] = B[0]; rho[0] = Rr[0]
+    th[1] = B[1] * th[0] - AC[1]; rho[1] = th[0] * Rr[1] - A[1] * rho[0]
+    for i in range(2, n + 1):
+        th[i] = B[i] * th[i - 1] - AC[i] * th[i - 2]; rho[i] = th[i - 1] * Rr[i] - A[i] * rho[i - 1]
+    ph[n + 1] = 1; ph[n] = B[n]; sg[n] = Rr[n]
+    ph[n - 1] = B[n - 1] * ph[n] - AC[n]; sg[n - 1] = ph[n] * Rr[n - 1] - C[n - 1] * sg[n]
+    for i in range(n - 2, 0, -1):
+        ph[i] = B[i] * ph[i + 1] - AC[i + 1] * ph[i + 2]; sg[i] = ph[i + 1] * Rr[i] - C[i] * sg[i + 1]
+    rdet = dtype(1) / th[n]
+    y = np.zeros(n + 1, dtype)
+    y[0] = (ph[1] * rho[0] - C[0] * sg[1]) * rdet
+    for i in range(1, n):
+        y[i] = (ph[i + 1] * rho[i] - C[i] * th[i - 1] * sg[i + 1]) * rdet
+    y[n] = rho[n] * rdet
+    pL = np.array([y[0]] + [g("rc", w - 1) - y[w] for w in range(1, W)], dtype)
+    return pL, y[1:].astype(dtype)
+
+
+def solve(data, R, m, T=None, dtype=np.float64, info=None, xwave=0):
     """Returns (delta[2N] with J delta = -R computed with the device's elimination order, smallest pivot relative to
-    its terms)."""
+    its terms).  xwave = W > 1: the tree stops at W segments (the waves of a reach) and continuant_close takes over."""
     N = len(R) // 2
     assert m >= 2
     rows, (aU, bU, rU), i2t, i2c = scalar_rows(data, R, dtype)
@@ -126,7 +165,7 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
                R2=max(float(np.max(np.abs(r[1]))) for r in rec) if rec else 0.0, u1=float(np.max(np.abs(u1))))
     # 2. tree
     levels = []
-    while len(seg["u1"]) > 1:
+    while len(seg["u1"]) > max(1, xwave):
         X = {k: v[0::2] for k, v in seg.items()}
         Y = {k: v[1::2] for k, v in seg.items()}
         seg, el = merge(X, Y)
@@ -141,6 +180,10 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
         aux["A1"] = max(aux["A1"], float(np.max(np.abs(el["A1"])))); aux["A2"] = max(aux["A2"], float(np.max(np.abs(el["A2"]))))
         aux["d1d2"] = max(aux["d1d2"], float(np.max(np.abs(seg["d1"] / seg["d2"])))); aux["u1"] = max(aux["u1"], float(np.max(np.abs(seg["u1"]))))
         worst = min(worst, np.min(np.abs(el["det"]) / el["scale"]))
+    if xwave > 1 and len(seg["u1"]) == xwave:
+        assert np.all(seg["u2"] == 1)
+        pL, mR = continuant_close(seg, aU, bU, rU, dtype)
+        return _way_down(levels, pL, mR, rec, rc, i2t, i2c, N, T, m, dtype), worst
     S = {k: v[0] for k, v in seg.items()}
     # root: up  u1 p_0 + u2 m_0 + u3 m_last = ru ; down  d1 p_0 + d2 m_last = rd (nothing right of the last row) ; U row
     r = one / S["d2"]
@@ -154,6 +197,10 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
     p0 = (rU * S["u2"] - bU * e3) / det
     mlast = (S["rd"] - S["d1"] * p0) * r
     pL, mR = np.array([p0], dtype), np.array([mlast], dtype)
+    return _way_down(levels, pL, mR, rec, rc, i2t, i2c, N, T, m, dtype), worst
+
+
+def _way_down(levels, pL, mR, rec, rc, i2t, i2c, N, T, m, dtype):
     for el in reversed(levels):
         sep = -el["A1"] * pL + el["A2"] * mR + el["A3"]              # m of the left half's last row
         npL = np.empty(2 * len(pL), dtype); nmR = np.empty_like(npL)
@@ -171,4 +218,4 @@ def solve(data, R, m, T=None, dtype=np.float64, info=None):
     out = np.empty(2 * N, dtype)
     out[0::2] = (p + mv) * i2t
     out[1::2] = (p - mv) * i2c
-    return out, worst
+    return out

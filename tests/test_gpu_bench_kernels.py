@@ -159,3 +159,27 @@ def test_dispatch_prefers_the_most_specific_instantiation():
                 nodiag_exists = any(t["diag"] == 0 and all(t[k] == e[k] for k in ("dtype", "section_mode", "cells_per_thread",
                                     "waves_per_reach", "full", "boundary_class")) for t in A.kernel_table())
                 assert e["diag"] == (1 if history or not nodiag_exists else 0), (N, history, e)
+
+
+@pytest.mark.parametrize("spec", [("c4", "f64", 96, 121, 3, 1), ("c5", "f32", 128, 512, 3, 1), ("c5", "f64", 128, 512, 3, 1),
+                                  ("irr", "f64", 64, 128, 3, 1), ("long", "f64", 4, 16384, 2, 1)], ids=lambda s: f"{s[0]}-{s[1]}")
+def test_extra_workloads_of_the_bench_line(spec):
+    """bench.py's "workloads" entries (C4, C5 in both precisions, the polyline ensemble, long reaches), at a handful of reaches:
+    every entry launches the instantiation the full-size run launches (the dispatch does not depend on the reach count), converges
+    and carries the contract's fields; the full-size entries are what the driver's BENCH line holds."""
+    import importlib.util
+    from conftest import ROOT
+    sp = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(sp); sp.loader.exec_module(bench)
+    assert [s[:2] for s in bench.EXTRA_WORKLOADS] == [("c4", "f64"), ("c5", "f32"), ("c5", "f64"), ("irr", "f64"), ("long", "f64")]
+    full = {s[:2]: s for s in bench.EXTRA_WORKLOADS}[spec[:2]]
+    assert full[3] == spec[3]                                   # same node count as the driver-observed entry
+    w = bench.run_extra_workload(spec, 0)
+    assert w["all_converged"] and w["value"] > 0 and w["kernel_ms"] > 0 and w["reaches"] == spec[2] and w["nodes"] == spec[3]
+    r = w["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    real = 4 if spec[1] == "f32" else 8
+    assert abs(r["achieved"] - spec[2] * spec[4] * (4 * spec[3] * real + 40) / (w["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    k = w["kernel"]
+    want = {"c4": (2, 1, 0), "c5": (8, 1, 0), "irr": (2, 1, 0), "long": (8, 4, 1)}[spec[0]]
+    assert (k["cells_per_thread"], k["waves_per_reach"], k["long_reach"]) == want and (k["diag"] == 0 or k["long_reach"])

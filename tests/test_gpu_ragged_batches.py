@@ -1,0 +1,130 @@
+"""Ragged batches (fs_batch_set_reach_nodes) in the places the round-3 review found them treated as full ones, and the bound on
+the polyline stage tables.
+
+  * derive_fields_kernel (Solver.prepare_results, solver.py:65-127) interpolated the bed of RECT / TRAP_UNIFORM reaches over the
+    batch's N instead of the reach's own node count (the step kernels use the reach's own: Geometry::init) and wrote results for
+    slots past a reach's end from history that was never written;
+  * fs_batch_set_state filled the downstream half of the level-0 hydrograph row from column N - 1 (caller padding);
+  * fs_batch_restart's "storage needs its stage" guard looked at reach 0's kind only;
+  * fs_batch_set_geometry_irregular(_per_reach) staged stage tables of any size."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from oracle import preissmann_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-8
+
+
+def rel(a, b, floor):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+def _uniform_batch(probs, mode, N, node_counts=None, pad_value=-777.0, nodes_after_state=False):
+    """one RECT / TRAP_UNIFORM batch of prismatic problems with (optionally) ragged node counts; the state rows are padded with a
+    sentinel no kernel may ever look at"""
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+    B, p0 = len(probs), probs[0]
+    b = PreissmannBatch(B, N, p0.nt, section_mode=mode, history=True)
+    b.set_scheme(p0.theta, p0.dt, p0.dx, p0.tol, p0.max_iter)
+    b.set_geometry_uniform([p.geo["b_main"][0] for p in probs], [p.geo["n_main"][0] for p in probs], [p.geo["z_bed"][0] for p in probs],
+                           [p.geo["z_bed"][-1] for p in probs], side_slope=[p.geo["m_main"][0] for p in probs] if mode == "trap_uniform" else None)
+    if node_counts is not None and not nodes_after_state:
+        b.set_reach_nodes(node_counts)
+    b.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, np.stack([p.us.target for p in probs], axis=1)))
+    b.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=np.array([p.ds.bed_slope for p in probs]), bed_level=np.zeros(B))))
+    pad = lambda a: np.concatenate([a, np.full(N - len(a), pad_value)])
+    b.set_state(np.stack([pad(p.h0) for p in probs]), np.stack([pad(p.Q0) for p in probs]))
+    if node_counts is not None and nodes_after_state:
+        b.set_reach_nodes(node_counts)
+    return b
+
+
+@pytest.mark.parametrize("mode", ["rect_uniform", "trap_uniform"])
+def test_derived_fields_of_a_ragged_uniform_batch(mode):
+    from synth import rect_problem
+    lengths = [37, 90, 128, 61]
+    probs = []
+    for s, n in enumerate(lengths):
+        q = rect_problem(n, seed=700 + s, n_steps=4)
+        if mode == "trap_uniform":
+            q.geo["m_main"][:] = 1.5
+        probs.append(q)
+    N = max(lengths)
+    fields = ("level", "area", "top_width", "froude_number", "velocity", "wave_celerity", "amplitude")
+    with _uniform_batch(probs, mode, N, lengths) as b:
+        b.step(4)
+        assert np.all(b.status() == 0)
+        h, Q = b.history_arrays(0, 5)
+        d = b.derive(0, 5)
+    for r, (n, q) in enumerate(zip(lengths, probs)):
+        with _uniform_batch([q], mode, n) as one:                 # the reach alone, as a full batch of its own length
+            one.step(4)
+            d1 = one.derive(0, 5)
+            h1, _ = one.history_arrays(0, 5)
+        assert np.array_equal(h[:, r, :n], h1[:, 0]), (mode, n)         # (the step kernels were right before: same bits)
+        # the bed the oracle interpolates over the reach's OWN nodes (cross_section.py:887-900), not over the batch's N
+        bed = q.geo["z_bed"][0] * (1.0 - np.arange(n) / (n - 1)) + q.geo["z_bed"][-1] * (np.arange(n) / (n - 1))
+        assert np.max(np.abs(d["level"][:, r, :n] - h[:, r, :n] - bed[None, :])) <= 1e-12 * max(1.0, bed[0]), (mode, n)
+        for f in fields:
+            assert np.array_equal(d[f][:, r, :n], d1[f][:, 0]), (mode, n, f)
+            assert np.all(d[f][:, r, n:] == 0.0), (mode, n, f)            # slots past the reach's end: zero, not derived garbage
+        assert np.array_equal(d["peak_amplitude"][r, :n], d1["peak_amplitude"][0]) and np.all(d["peak_amplitude"][r, n:] == 0.0)
+
+
+@pytest.mark.parametrize("nodes_after_state", [False, True])
+def test_level0_hydrograph_row_holds_each_reachs_last_node(nodes_after_state):
+    from synth import rect_problem
+    lengths = [20, 64, 33]
+    probs = [rect_problem(n, seed=800 + s, n_steps=2, steady=False) for s, n in enumerate(lengths)]
+    for q in probs:                                          # a sloping initial profile: the last node differs from its neighbours
+        q.h0 = q.h0 * (1.0 + 0.05 * np.arange(q.N) / q.N)
+    with _uniform_batch(probs, "rect_uniform", 64, lengths, nodes_after_state=nodes_after_state) as b:
+        row = b.hydrographs(0, 1)[0]
+        for r, q in enumerate(probs):
+            assert row[0, r] == q.h0[0] and row[1, r] == q.Q0[0]
+            assert row[2, r] == q.h0[-1] and row[3, r] == q.Q0[-1], (r, row[2, r], q.h0[-1])
+
+
+def test_restart_with_per_reach_kinds_needs_the_storage_stage_whichever_reach_has_the_storage():
+    from fixture_batch import hetero_batch_from_problems
+    from flowsim_amd import _abi as A
+    # two channels of the reference's random sweep: reach 0 ends in a fixed depth, reach 1 in a LumpedStorage (closed form)
+    sweep = {i: (fx, m) for i, fx, m in O.sweep_cases(os.path.join(GOLDEN, "random_sweep.npz"))}
+    p_plain, p_store = (O.problem_from_fixture(*sweep[i]) for i in (14, 11))
+    assert p_plain.ds.storage is None and p_store.ds.storage is not None and min(p_plain.nt, p_store.nt) >= 4
+    with hetero_batch_from_problems([p_plain, p_store]) as b:
+        b.step(2)
+        assert np.all(b.status() == 0)
+        h, Q = b.state(); hg, Qg = b.guess(); Y = b.storage_stage()
+        with hetero_batch_from_problems([p_plain, p_store]) as c:
+            with pytest.raises(A.FlowsimError, match="storage"):
+                c.restart(2, h, Q, hg, Qg)                             # reach 1 would go on from stage 0
+            c.restart(2, h, Q, hg, Qg, storage_stage=Y)
+            c.step(1)
+            b.step(1)
+            assert np.all(c.status() == 0)
+            assert np.array_equal(c.hydrographs(3, 1), b.hydrographs(3, 1))
+
+
+def test_stage_tables_beyond_the_bound_fall_back_to_the_edge_walk(monkeypatch):
+    from fixture_batch import batch_from_problems
+    fx, meta = O.load_fixture(os.path.join(GOLDEN, "irr_levee.npz"))
+    p = O.problem_from_fixture(fx, meta)
+    p.nt = 9
+    res = {}
+    for cap in (None, "4096"):
+        if cap:
+            monkeypatch.setenv("FS_POLY_TABLE_MAX_BYTES", cap)
+        with batch_from_problems([p], mode="irregular") as b:
+            assert b.poly_tables() == (0 if cap else 1)
+            b.step(p.nt - 1)
+            assert np.all(b.status() == 0)
+            res[cap] = b.history_arrays(0, p.nt) + (b.iterations(0, p.nt),)
+    for h, Q, its in res.values():
+        assert rel(h[:, 0], fx["depth"][:9], 1e-3) <= TOL and rel(Q[:, 0], fx["flow"][:9], 1.0) <= TOL
+        assert np.array_equal(its[:, 0], fx["iters"][:9])

@@ -31,7 +31,7 @@ def run(*cmd):
 
 def check_object(obj, tmp):
     bundle, co = os.path.join(tmp, "f.bundle"), os.path.join(tmp, "f.co")
-    run(f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={bundle}", obj)
+    run(f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={bundle}", obj, os.path.join(tmp, "copy.o"))      # (no output name: objcopy rewrites its input)
     run(f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={TARGET}", f"--input={bundle}", f"--output={co}")
     problems = []
     funcs, descriptors = [], set()

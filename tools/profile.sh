@@ -1,15 +1,15 @@
 #!/bin/bash
-# rocprofv3 passes for profiles/round3:  tools/profile.sh TAG <bench.py arguments ...>
+# rocprofv3 passes for profiles/round4:  tools/profile.sh TAG <bench.py arguments ...>
 #   kernel trace + stats, then the HBM traffic counters in separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
 #   do not fit one pass; counters are never combined with system traces), the issue counters and the flop counters.
-# Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round3/.
+# Everything lands under gpurun_out/prof/TAG; tools/refresh_profiles.py TAG condenses it into profiles/round4/.
 set -e; mkdir -p $(pwd)/gpurun_out/prof
 TAG=$1; shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof/$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="$* --no-cpu-baseline"
+ARGS="$* --no-cpu-baseline --no-extras"
 echo "$ARGS" > $OUT/args.txt
 sha256sum $ROOT/flow-sim_amd/csrc/libflowsim_hip.so | cut -d' ' -f1 > $OUT/library_sha256.txt
 pass() { name=$1; shift; rocprofv3 "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$name.json 2> $OUT/$name.err || true; }

@@ -16,7 +16,7 @@ import argparse, csv, glob, json, os, shutil, sys
 ap = argparse.ArgumentParser()
 ap.add_argument("tag")
 ap.add_argument("--kernel", default="preissmann")
-ap.add_argument("--round", default="round3")
+ap.add_argument("--round", default="round4")
 ap.add_argument("--second", default=None,
                 help="tag of a second run of the same workload with another number of levels in its launch: the two together give the "
                      "part of the traffic that does not depend on the levels (state in, state out) and the part per level")
