@@ -39,6 +39,7 @@ FS_LIST_TRAP(FS_DECLARE, double, FS_F64) FS_LIST_TRAP(FS_DECLARE, float, FS_F32)
 FS_LIST_TABLE(FS_DECLARE, double, FS_F64) FS_LIST_TABLE(FS_DECLARE, float, FS_F32)
 FS_LIST_IRREGULAR(FS_DECLARE)
 FS_LIST_NODIAG(FS_DECLARE_NODIAG)
+FS_LIST_TAIL(FS_DECLARE_TAIL)
 FS_LIST_LONG(FS_DECLARE_LONG)
 #endif
 
@@ -77,7 +78,7 @@ typedef const void *KernelPtr;
 // full   == 1: no per-row selects, valid only for N = 64*W*M
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
-struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int longk; };   // diag == 0: no history / trace stores; longk: fs_long.hpp
+struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int longk; int tail = -1; };   // diag == 0: no history / trace stores; longk: fs_long.hpp; tail >= 0: tail-only form, (N - 1) mod M == tail
 #define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
   { DT, SEC, M, W, FULL, (int)(BCK), 1, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,          \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>, 0 },
@@ -87,6 +88,9 @@ struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp;
 #define FS_TABLE_ROW_NODIAG(R, DT, SEC, M, W, FULL, BCK)                                       \
   { DT, SEC, M, W, FULL, (int)(BCK), 0, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK), false>,    \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), false>, 0 },
+#define FS_TABLE_ROW_TAIL(R, DT, SEC, M, W, BCK, TAIL)                                            \
+  { DT, SEC, M, W, 0, (int)(BCK), 0, &fs_launch<R, SEC, M, W, true, (int)(BCK), false, TAIL>,      \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), false, TAIL>, 0, TAIL },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -103,6 +107,9 @@ const Entry kEntries[] = {FS_LIST_IRREGULAR(FS_TABLE_ROW)};
 const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 8, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND))
+#ifndef FS_NO_TAIL
+                          FS_LIST_TAIL(FS_TABLE_ROW_TAIL)
+#endif
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH))
                           FS_ENTRY_X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, true)
@@ -125,7 +132,8 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
-                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG) FS_LIST_LONG(FS_TABLE_ROW_LONG)};
+                          FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG) FS_LIST_LONG(FS_TABLE_ROW_LONG)
+                          FS_LIST_TAIL(FS_TABLE_ROW_TAIL)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
@@ -135,7 +143,8 @@ constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 // hetero: bit 0 = per-reach node counts (ragged kernels only), bit 1 = per-reach scheme or boundary kinds (kernels that read
 // them: boundary classes 0 and -1)
 bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, bool need_diag, bool need_any, int hetero = 0) {
-  if ((hetero & 1) && e.full) return false;
+  if ((hetero & 1) && (e.full || e.tail >= 0)) return false;      // per-reach node counts: the boundary row's place differs from reach to reach
+  if (e.tail >= 0 && (N - 1) % e.M != e.tail) return false;
   if ((hetero & 2) && e.bck > 0) return false;
   const bool light = fs::bc_is_light(usk) && fs::bc_is_light(dsk);
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
@@ -172,7 +181,7 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
     if (general_only && (!e.diag || e.bck >= 2)) continue;
     if (wantM && (e.M != wantM || e.W != wantW)) continue;
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
-    auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8); };
+    auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8) + (x.tail >= 0 ? 16 : 0); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
     if (best && e.longk != best->longk) {      // a kernel that keeps the reach on chip whenever one fits
       if (!e.longk) best = &e;
@@ -1359,6 +1368,8 @@ int fs_kernel_table_entry(int32_t i, int32_t *out) {
 }
 
 int32_t fs_batch_kernel_index(fs_batch *b) { return (b && b->kern) ? (int32_t)(b->kern - kEntries) : -1; }
+
+int32_t fs_kernel_table_entry_tail(int32_t i) { return (i >= 0 && i < kNumEntries) ? kEntries[i].tail : -2; }
 
 int32_t fs_batch_poly_tables(fs_batch *b) { return (b && b->poly_x) ? (b->poly_K > 0 ? 1 : 0) : -1; }
 

@@ -12,10 +12,10 @@
 
 typedef void (*FsLaunchFn)(const void *args, int B, hipStream_t st);
 
-template <typename R, int SEC, int M, int W, bool RAGGED, int BCK, bool DIAG = true>
+template <typename R, int SEC, int M, int W, bool RAGGED, int BCK, bool DIAG = true, int TAIL = -1>
 void fs_launch(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG>), dim3(B), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG, TAIL>), dim3(B), dim3(64 * W), 0, st, a);
 }
 
 template <typename R, int SEC, int M, int W, int BCK>
@@ -110,6 +110,19 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
   X(double, FS_F64, FS_SEC_TABLE, 2, 1, 0, FS_BCK(FS_BC_RATING_BLEND)) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, 0) \
   X(double, FS_F64, FS_SEC_IRREGULAR, 2, 1, 0, FS_BCK(FS_BC_NORMAL_DEPTH))
+
+// The ensemble shape of BASELINE configs[3] (cases/gerd_roseires: 121 nodes in a 128-row lane grid, gate curve downstream) in its
+// tail-only form (fs_kernel.hpp, TAIL): X(R, DT, SEC, M, W, BCK, TAIL), TAIL = (N - 1) mod M = the local row of the boundary row;
+// ragged, no diagnostics; a batch with per-reach node counts takes the general ragged kernel instead
+#define FS_LIST_TAIL(X) \
+  X(double, FS_F64, FS_SEC_TABLE, 2, 1, FS_BCK(FS_BC_RATING_BLEND), 0) \
+  X(double, FS_F64, FS_SEC_TABLE, 2, 1, FS_BCK(FS_BC_RATING_BLEND), 1)
+#define FS_INSTANTIATE_TAIL(R, DT, SEC, M, W, BCK, TAIL)                                                                    \
+  template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), false, TAIL>(const fs::KernelArgs<R>); \
+  template void fs_launch<R, SEC, M, W, true, (int)(BCK), false, TAIL>(const void *, int, hipStream_t);
+#define FS_DECLARE_TAIL(R, DT, SEC, M, W, BCK, TAIL)                                                                               \
+  extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), false, TAIL>(const fs::KernelArgs<R>); \
+  extern template void fs_launch<R, SEC, M, W, true, (int)(BCK), false, TAIL>(const void *, int, hipStream_t);
 
 // explicit instantiation (fs_part_*.hip) / extern declaration (fs_abi.hip) of one entry
 #define FS_INSTANTIATE(R, DT, SEC, M, W, FULL, BCK)                                                            \

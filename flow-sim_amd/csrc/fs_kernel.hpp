@@ -476,9 +476,18 @@ template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() 
 // RAGGED = false promises N = 64 W M: every row is a cell but the very last one, which is the boundary row.
 // DIAG = false: no per-level history and no residual trace (batches created without FS_FLAG_HISTORY / FS_FLAG_TRACE): the
 // stores are never executed there, but compiled in they cost the flagship kernel 1.1 %
-template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true>
+// TAIL >= 0 (ragged one-wave kernels only; round 4): "every row a cell except in the tail lanes".  The batch's N is not the lane grid's,
+// but the position of the downstream boundary row inside its lane is known at compile time (local row TAIL = (N - 1) mod M), so the
+// per-row selects of the ragged form are gone: every row is assembled as a cell; in local row TAIL one select per number - taken by
+// the ONE lane that owns node N - 1 - puts the boundary row in; the rows beyond it are not replaced by identity rows but left as the
+// cells of clamped, frozen copies of node N - 1 ("phantom" cells: finite, diagonally dominant, and behind a boundary row whose
+// super-diagonal is zero, so nothing upstream of it ever reads them - the real unknowns get the very bits of the ragged kernel);
+// two lane masks hoisted out of the time loop keep the phantom rows out of the residual norm and the phantom nodes where they are.
+template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true, int TAIL = -1>
 __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
   static_assert(M >= 2, "a lane's segment needs two rows (its up and its down row)");
+  constexpr bool kTail = TAIL >= 0;
+  static_assert(!kTail || (RAGGED && W == 1 && TAIL < M && SEC == FS_SEC_TABLE && BCK >= 2), "tail-only form: ragged one-wave table kernels compiled for a boundary pair");
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
   // Short general-section kernels keep (A, Se, Q/A) of every node of the current fold in LDS: if the iterate is accepted they
@@ -504,7 +513,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   const int N = (RAGGED && a.reach_nodes) ? a.reach_nodes[reach] : a.N, NC = N - 1;
   const int s0 = t * M;                       // first node / row of this lane
   const int tD = RAGGED ? NC / M : T - 1;     // lane that owns node N-1 and the downstream boundary row ...
-  const int jD = RAGGED ? NC - tD * M : M - 1;   // ... as its local node / row jD (0..M-1)
+  const int jD = kTail ? TAIL : (RAGGED ? NC - tD * M : M - 1);   // ... as its local node / row jD (0..M-1; tail-only form: fs_abi.hip picks the instantiation with TAIL = NC mod M)
+  // tail-only form: 1.0 in the lanes up to / before the one that owns node N - 1, else 0.0 (multiplied in, never selected on)
+  const R mle = (kTail && t > tD) ? R(0) : R(1), mlt = (kTail && t >= tD) ? R(0) : R(1);
   const size_t base = (size_t)reach * NS;
 
   Geo geo;
@@ -829,6 +840,15 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
             row.rho0 = fma_(ga, Cres, -Mres);             // qm - ga rc with qm = -Mres, rc = -Cres
             row.rc = -Cres;
             R r2 = fma_(Cres, Cres, Mres * Mres);
+            if constexpr (kTail) {
+              if (c == TAIL) {                 // the boundary row, in the one lane that owns node N - 1 (its residual was added in step 1)
+                const bool isD = t == tD;
+                const R x = Drow.dh * i2tL, y = Drow.dq * i2c;
+                row.al = isD ? x + y : row.al; row.D = isD ? x - y : row.D; row.de = isD ? R(0) : row.de;
+                row.rho0 = isD ? -Drow.res : row.rho0; row.rc = isD ? R(0) : row.rc;
+              }
+              nrm2 = fma_(r2, c < TAIL ? mle : mlt, nrm2);    // cells only: not the boundary row, not the phantom cells behind it
+            } else
             // rows beyond the cells: the downstream boundary row (on p and m of node N-1), then identity rows
             if (RAGGED || c == M - 1) {
               const int k = s0 + c;
@@ -848,7 +868,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
                 row.rho0 = bcr ? -Dr.res : R(0); row.rc = R(0);
               }
             }
-            nrm2 += r2;
+            if constexpr (!kTail) nrm2 += r2;
           }
           if (c == 0) {
             seg.d1 = row.al; seg.d2 = row.D; seg.d3 = row.de; seg.rd = row.rho0;
@@ -1261,6 +1281,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           // p of its first row is (this rc) - (this m), and both copies of the shared node must move by the same bits
           const R pM = rcLast - mR;
           dh[M] = (pM + mB) * i2t_of(M); dQ[M] = (pM - mB) * i2c;
+          if constexpr (kTail) { dh[M] *= mlt; dQ[M] *= mlt; }       // (node M > TAIL always: a phantom node from the owner lane on)
         }
 #pragma unroll
         for (int j = M - 1; j >= 1; --j) {
@@ -1268,9 +1289,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           const R mprev = j == 1 ? mA : fma_(-el[j - 1].R2.get(), mj, fma_(-el[j - 1].R1.get(), pL, el[j - 1].R3.get()));
           const R pj = rc_of(j - 1) - mprev;
           dh[j] = (pj + mj) * i2t_of(j); dQ[j] = (pj - mj) * i2c;
+          if constexpr (kTail) { dh[j] *= (j <= TAIL ? mle : mlt); dQ[j] *= (j <= TAIL ? mle : mlt); }     // phantom nodes stay where they are
           mj = mprev;
         }
         dh[0] = (pL + mA) * i2t_of(0); dQ[0] = (pL - mA) * i2c;
+        if constexpr (kTail) { dh[0] *= mle; dQ[0] *= mle; }
       }
       FS_T(6);
       if constexpr (((sizeof(R) == 4 ? FS_PHASE_FENCE_F32 : FS_PHASE_FENCE) & 8) != 0) {

@@ -2,3 +2,4 @@
 #include "fs_entries.hpp"
 
 FS_LIST_NODIAG(FS_INSTANTIATE_NODIAG)
+FS_LIST_TAIL(FS_INSTANTIATE_TAIL)

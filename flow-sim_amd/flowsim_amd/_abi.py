@@ -88,6 +88,7 @@ SIGNATURES = {
     "fs_kernel_table_entry": (C.c_int, [C.c_int32, _I]),
     "fs_batch_kernel_index": (C.c_int32, [_P]),
     "fs_batch_poly_tables": (C.c_int32, [_P]),
+    "fs_kernel_table_entry_tail": (C.c_int32, [C.c_int32]),
 }
 
 _lib = None
@@ -139,5 +140,5 @@ def kernel_table():
     for i in range(l.fs_kernel_table_size()):
         v = (C.c_int32 * 8)()
         check(l.fs_kernel_table_entry(i, v), "kernel_table")
-        out.append(dict(zip(KERNEL_FIELDS, (int(x) for x in v)), index=i))
+        out.append(dict(zip(KERNEL_FIELDS, (int(x) for x in v)), index=i, tail=int(l.fs_kernel_table_entry_tail(i))))
     return out

@@ -102,6 +102,7 @@ class PreissmannSolver(Solver):
             elif nt > 1:
                 b.step(nt - 1)
             status = int(b.status()[0])
+            self.kernel_entry = A.kernel_table()[b.kernel_index()] if nt > 1 else None      # the instantiation that ran (diagnostic)
             self.ill_conditioned = status == A.ILL_CONDITIONED
             if self.ill_conditioned:
                 status = A.OK                      # a warning: the run is complete

@@ -305,6 +305,10 @@ int fs_batch_kernel_info(fs_batch *b, int32_t *cells_per_thread, int32_t *waves_
 int32_t fs_kernel_table_size(void);
 int fs_kernel_table_entry(int32_t i, int32_t *out);
 int32_t fs_batch_kernel_index(fs_batch *b);
+/* entry i in its tail-only form (round 4: ragged, but compiled for the local row the downstream boundary row takes in its lane):
+ * that row, (N - 1) mod M, or -1 for every other entry (-2: no such entry).  fs_batch_step only picks such an entry for a batch
+ * whose one node count gives that row. */
+int32_t fs_kernel_table_entry_tail(int32_t i);
 /* FS_SEC_IRREGULAR: 1 when the batch evaluates its polylines from stage tables, 0 when it walks their edges (the same results at
  * about five times the instructions): the tables take about 10 KB per node at 40 stations, per channel, and
  * fs_batch_set_geometry_irregular(_per_reach) leaves them out beyond FS_POLY_TABLE_MAX_BYTES (environment, default 8 GiB) or with

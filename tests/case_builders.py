@@ -281,7 +281,15 @@ def gerd_gates():
     return solver, S.tolerance
 
 
-HOST_ROW_BUILDERS = {"storage_callable_rc": storage_callable_rc, "gerd_gates": gerd_gates}
+def gerd_gates_long():
+    """the same gates on a reach longer than a table kernel keeps on chip: dx = 50 m, 2 409 nodes, 30 levels (tests/golden/gerd_gates_long.npz)"""
+    from cases.gerd_roseires.model import build
+    from cases.gerd_roseires import settings as S
+    solver, _ = build(inflow_hyd_func=None, sim_duration=30 * 3600, inflow_scale=8.0, smooth_gates=False, spatial_step=50.0)
+    return solver, S.tolerance
+
+
+HOST_ROW_BUILDERS = {"storage_callable_rc": storage_callable_rc, "gerd_gates": gerd_gates, "gerd_gates_long": gerd_gates_long}
 
 
 def storage_curve_poly_losses():

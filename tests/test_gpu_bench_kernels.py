@@ -133,8 +133,39 @@ def test_gerd_roseires_over_all_384_levels_against_the_reference(chunks):
         assert np.all(b.status() == 0)
         e = entry_of(b)
         assert (e["cells_per_thread"], e["waves_per_reach"], e["diag"]) == (2, 1, 0)
-        assert e["boundary_class"] == 2 + A.BC_RATING_BLEND
+        assert e["boundary_class"] == 2 + A.BC_RATING_BLEND and e["tail"] == 0       # 121 nodes: the boundary row is local row 0 of lane 60
         check_rows(b, fx["depth"], fx["flow"], fx["iters"])
+
+
+def test_the_tail_only_form_gives_the_bits_of_the_ragged_kernel(monkeypatch):
+    """<double, TABLE, 2, 1, gate curve, DIAG = false, TAIL = 0> (round 4: every row a cell but the boundary row's lane) against the
+    general ragged instantiation of the same shape: the rows behind the boundary row are phantom cells there and identity rows here,
+    and neither can reach a real unknown (the boundary row's super-diagonal is zero) - hydrographs, state, start vector and counts are
+    bit-identical over 48 levels of cases/gerd_roseires and over an 8-member Manning-n ensemble."""
+    from fixture_batch import batch_from_problems
+    from flowsim_amd import _abi as A
+    table = A.kernel_table()
+    plain = [e["index"] for e in table if e["section_mode"] == A.SEC_TABLE and e["dtype"] == A.F64 and (e["cells_per_thread"], e["waves_per_reach"]) == (2, 1)
+             and e["boundary_class"] == 2 + A.BC_RATING_BLEND and e["diag"] == 0 and e["tail"] == -1]
+    assert len(plain) == 1
+    for name, B in (("gerd", 1), ("gerd_ensemble", 8)):
+        fx, meta = O.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+        probs = [O.problem_from_fixture(fx, meta, m) for m in (range(B) if meta.get("B") else [None])]
+        override = [float(p.geo["n_main"][0]) for p in probs] if B > 1 else None
+        out = {}
+        for forced in (None, plain[0]):
+            if forced is not None:
+                monkeypatch.setenv("FS_KERNEL_INDEX", str(forced))
+            with batch_from_problems(probs, mode="table", history=False, n_main_override=override) as b:
+                b.step(probs[0].nt - 1)
+                assert np.all(b.status() == 0)
+                e = table[b.kernel_index()]
+                assert e["tail"] == (0 if forced is None else -1)
+                out[forced] = (b.hydrographs(0, probs[0].nt), b.state(), b.guess(), b.iterations(0, probs[0].nt))
+            monkeypatch.delenv("FS_KERNEL_INDEX", raising=False)
+        a, c = out[None], out[plain[0]]
+        assert np.array_equal(a[0], c[0]) and np.array_equal(a[3], c[3])
+        assert all(np.array_equal(x, y) for x, y in zip(a[1] + a[2], c[1] + c[2]))
 
 
 def test_dispatch_prefers_the_most_specific_instantiation():

@@ -135,6 +135,12 @@ def test_plugins_without_a_device_form_run_through_host_rows(name):
     if name == "gerd_gates":       # the gates did move: the outflow jumps by an order of magnitude and comes back
         q = solver.flow[:, -1]
         assert q[26] < 2200 and q[27] > 15000 and q[36] < 2200
+    elif name == "gerd_gates_long":
+        # 2 409 nodes: more than a table kernel keeps on chip - the multi-pass kernel with its iteration budget (fs_long.hpp), one
+        # Newton iteration per launch, the gate row evaluated by the mirror's RoseiresRatingCurve in between
+        assert solver.number_of_nodes == 2409 and solver.kernel_entry["long_reach"] == 1 and solver.kernel_entry["boundary_class"] == -1
+        q = solver.flow[:, -1]
+        assert q[26] < 2200 and q[27] > 15000                      # the gates open here as they do at dx = 1 000 m
     else:
         st = solver.channel.downstream_boundary.lumped_storage
         got = np.array(st.stage_hydrograph)[1:, 1]

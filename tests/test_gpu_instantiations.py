@@ -39,7 +39,8 @@ TABLE = _table()
 def _id(e):
     sec = ("rect", "trap", "table", "irr")[e["section_mode"]]
     return (f"{e['index']:03d}-{'f64' if e['dtype'] == 0 else 'f32'}-{sec}-{e['cells_per_thread']}x{e['waves_per_reach']}"
-            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-long' if e.get('long_reach') else ''}")
+            f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-long' if e.get('long_reach') else ''}"
+            f"{'-tail%d' % e['tail'] if e.get('tail', -1) >= 0 else ''}")
 
 
 def _nodes(e):
@@ -48,7 +49,10 @@ def _nodes(e):
         return 2 * cap + cap // 3 + e["index"] % 7            # the multi-pass kernel (fs_long.hpp): three passes, the last one ragged
     if e["full"]:
         return cap
-    return max(2, cap - 1 - e["index"] % 5)          # ragged: 1..5 rows short of the capacity
+    n = max(2, cap - 1 - e["index"] % 5)             # ragged: 1..5 rows short of the capacity
+    while e.get("tail", -1) >= 0 and (n - 1) % e["cells_per_thread"] != e["tail"]:
+        n -= 1                                       # tail-only form: the boundary row sits in local row `tail` of its lane
+    return n
 
 
 # boundary pairs for the general classes, rotated over the entries: (upstream, downstream)
@@ -152,6 +156,8 @@ def case_for(e):
             return fixture_problem(name, 10), "table", None
         if bck >= 2:
             assert bck - 2 == A.BC_RATING_BLEND and cap >= 120
+            if e.get("tail", -1) == 1:      # an even node count: a prismatic trapezoid described as a table, blended rating curve downstream
+                return prismatic_problem(e, ("flow", "blend"), True), "table", None
             return fixture_problem("gerd", 6), "table", None
         # class 0: compound sections going over bank where the capacity allows, else the table of a plain trapezoid
         # (fp32 cannot take the central difference of the Roseires gate curve: 1 mm on a stage of 487 m is 30 ulp)
@@ -229,6 +235,8 @@ def second_case_for(e):
         pair = GENERAL_PAIRS[(e["index"] + 4) % len(GENERAL_PAIRS)]
         return prismatic_problem(e, pair, e["index"] % 2 == 1, n_steps=3), "table", None
     if sec == A.SEC_TABLE and bck >= 2:
+        if e.get("tail", -1) == 1:
+            return prismatic_problem(dict(e, index=e["index"] + 2), ("flow", "blend"), False, n_steps=5), "table", None
         return fixture_problem("gerd_ensemble", 5, member=e["index"] % 8), "table", None
     pool = (SECOND_TABLE if sec == A.SEC_TABLE else SECOND_POLY)[min(bck, 2)]
     fits = [i for i in pool if SWEEP[i][1]["N"] <= cap]
