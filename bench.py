@@ -12,7 +12,7 @@ tolerance 1e-6.  One "step" = one time level (full Newton loop) of every reach i
 Weak scaling (default): every rank owns its own block of --reaches reaches (global reach index seeds
 the draws).  Strong scaling (--total-reaches T): T reaches in all, split into contiguous blocks over
 the ranks (flowsim_amd.shard.split_reaches; north_star quotes 65 536 reaches in total at 8 GPUs).  The
-only collective is one RCCL all_gather of the boundary hydrographs, inside the timed region.  Inputs
+only collective is one RCCL gather of the boundary hydrographs to rank 0, inside the timed region.  Inputs
 are resident in HBM before the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
@@ -68,7 +68,8 @@ def load_profile(workload, dtype, N, entry):
     if not os.path.exists(path):
         return None
     p = json.load(open(path))
-    same_kernel = all(p["kernel"].get(k) == entry[k] for k in ("cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag"))
+    same_kernel = all(p["kernel"].get(k) == entry[k] for k in ("cells_per_thread", "waves_per_reach", "full", "boundary_class", "diag")) \
+        and p["kernel"].get("table_index", entry["index"]) == entry["index"]
     if p.get("library_sha256") != library_sha256() or p.get("nodes") != N or not same_kernel:
         return None
     p["file"] = os.path.relpath(path, ROOT)
@@ -289,7 +290,9 @@ def roofline_blocks(workload, dtype, N, B, K, kern_ms, its_sum, entry):
             "kernel": "preissmann_long_kernel" if entry.get("long_reach") else "preissmann_step_kernel", "kernel_ms": kern_ms, "launches": 1,
             "algorithmic_bytes_per_reach_timestep": 4 * N * real + 40,
             "note": ("multi-pass kernel: the Newton vector passes through HBM every iteration, see DESIGN.md section 4.5" if entry.get("long_reach")
-                     else "VALU-issue bound, not HBM bound: the levels between load and store never touch HBM, see DESIGN.md section 4")}
+                     else ("a team of workgroups per reach, each holding 64 W M rows on chip, one exchange through device memory per Newton "
+                           "iteration: see DESIGN.md section 4.5" if entry.get("team")
+                           else "VALU-issue bound, not HBM bound: the levels between load and store never touch HBM, see DESIGN.md section 4"))}
     comp = None
     if prof is not None and prof.get("flops_per_reach_iteration"):
         tf = prof["flops_per_reach_iteration"] * float(its_sum) / (kern_ms * 1e-3) / 1e12
@@ -321,7 +324,7 @@ def run_extra_workload(spec, local):
         return {"workload": desc, "name": workload, "dtype": dtype, "value": B * K / el, "unit": "reach-timesteps/s", "steps": K, "warmup": Wm,
                 "reaches": B, "nodes": N, "ms_per_step": el * 1e3 / K, "kernel_ms": kern_ms,
                 "kernel": dict(info, table_index=kidx, boundary_class=entry["boundary_class"], full=entry["full"], diag=entry["diag"],
-                               long_reach=entry.get("long_reach", 0)),
+                               long_reach=entry.get("long_reach", 0), team=entry.get("team", 0)),
                 "mean_newton_iterations_per_step": float(its.sum()) / (B * K), "all_converged": bool(np.all(st == 0)),
                 "roofline": roof, "roofline_compute": comp}
     finally:
@@ -419,21 +422,22 @@ def main():
         # untimed rehearsal of the one collective of the path (same shape): communicator channels and
         # RCCL's staging buffers are set up on first use
         warm = hyd_dev[1:1 + K] if args.backend == "nccl" else hyd_dev[1:1 + K].cpu()
-        gather_hydrographs_split(warm, args.total_reaches, world) if strong else gather_hydrographs(warm, world)
+        gather_hydrographs_split(warm, args.total_reaches, world, 0) if strong else gather_hydrographs(warm, world, 0)
     barrier()
     t0 = time.perf_counter()
     batch.step(K, sync=False)
     batch.sync()
-    # the only exchange of the path: boundary hydrographs of the timed levels, [K, 4, all reaches] on every rank
+    # the only exchange of the path: boundary hydrographs of the timed levels, gathered as [K, 4, all reaches] on rank 0 (every other
+    # rank sends its [K, 4, B] block straight to it: one xGMI hop, 1 / world of the bytes an all_gather would move through every rank)
     timed_rows = hyd_dev[Wm + 1:Wm + 1 + K]
     if args.backend != "nccl" and world > 1:
         timed_rows = timed_rows.cpu()
     if strong:
-        gathered = gather_hydrographs_split(timed_rows, args.total_reaches, world)
-        assert gathered.shape == (K, 4, args.total_reaches)
+        gathered = gather_hydrographs_split(timed_rows, args.total_reaches, world, 0)
+        assert rank != 0 or gathered.shape == (K, 4, args.total_reaches)
     else:
-        gathered = gather_hydrographs(timed_rows, world)
-        assert gathered.shape == (K, 4, world * B)
+        gathered = gather_hydrographs(timed_rows, world, 0)
+        assert rank != 0 or gathered.shape == (K, 4, world * B)
     barrier()
     el = time.perf_counter() - t0
     kern_ms = batch.last_step_ms()
@@ -499,7 +503,8 @@ def main():
                        "reaches_per_gpu": B, "total_reaches": int(it_t[2].item()), "nodes": N, "parallelism": f"reach-sharded x{world}",
                        "mean_newton_iterations_per_step": mean_its, "all_converged": bool(it_t[1].item() == world),
                        "status_counts_rank0": status_counts,
-                       "kernel": dict(info, table_index=kidx, boundary_class=entry["boundary_class"], full=entry["full"], diag=entry["diag"]),
+                       "kernel": dict(info, table_index=kidx, boundary_class=entry["boundary_class"], full=entry["full"], diag=entry["diag"],
+                                      long_reach=entry.get("long_reach", 0), team=entry.get("team", 0), tail=entry.get("tail", -1)),
                        "kernel_ms_max_over_ranks": kern_ms_max,
                        "collective_world_size": dist.get_world_size() if world > 1 else 1, "ranks": ranks},
             "roofline": roof,

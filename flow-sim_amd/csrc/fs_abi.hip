@@ -41,6 +41,7 @@ FS_LIST_IRREGULAR(FS_DECLARE)
 FS_LIST_NODIAG(FS_DECLARE_NODIAG)
 FS_LIST_TAIL(FS_DECLARE_TAIL)
 FS_LIST_LONG(FS_DECLARE_LONG)
+FS_LIST_TEAM(FS_DECLARE_TEAM)
 #endif
 
 namespace {
@@ -78,7 +79,7 @@ typedef const void *KernelPtr;
 // full   == 1: no per-row selects, valid only for N = 64*W*M
 // bck: boundary-kind class the kernel is compiled for (fs_kernel.hpp): -1 any, 0 any but FS_BC_STORAGE_CURVE,
 //      1 RECT_UNIFORM with bc_is_light() kinds on both ends, 2 + k flow hydrograph upstream and kind k downstream
-struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int longk; int tail = -1; };   // diag == 0: no history / trace stores; longk: fs_long.hpp; tail >= 0: tail-only form, (N - 1) mod M == tail
+struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp; int longk; int tail = -1; int team = 0; };      // team: a reach as a team of workgroups (fs_kernel.hpp)   // diag == 0: no history / trace stores; longk: fs_long.hpp; tail >= 0: tail-only form, (N - 1) mod M == tail
 #define FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)                                             \
   { DT, SEC, M, W, FULL, (int)(BCK), 1, &fs_launch<R, SEC, M, W, !(FULL), (int)(BCK)>,          \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK)>, 0 },
@@ -91,6 +92,9 @@ struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp;
 #define FS_TABLE_ROW_TAIL(R, DT, SEC, M, W, BCK, TAIL)                                            \
   { DT, SEC, M, W, 0, (int)(BCK), 0, &fs_launch<R, SEC, M, W, true, (int)(BCK), false, TAIL>,      \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), false, TAIL>, 0, TAIL },
+#define FS_TABLE_ROW_TEAM(R, DT, SEC, M, W, BCK)                                                  \
+  { DT, SEC, M, W, 0, (int)(BCK), 1, &fs_launch_team<R, SEC, M, W, (int)(BCK)>,                    \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), true, -1, true>, 0, -1, 1 },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -127,13 +131,18 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
                           FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_TRAP_UNIFORM, 8, 1, 1, FS_BCK(FS_BC_RATING_POWER))
                           FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
                           FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)
-                          FS_TABLE_ROW_LONG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0)};
+                          FS_TABLE_ROW_LONG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0)
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1)
+#ifdef FS_TEAM_8X4
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1)
+#endif
+                          };
 #else
 const Entry kEntries[] = {FS_LIST_RECT(FS_TABLE_ROW, double, FS_F64) FS_LIST_TRAP(FS_TABLE_ROW, double, FS_F64)
                           FS_LIST_TABLE(FS_TABLE_ROW, double, FS_F64) FS_LIST_RECT(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_TRAP(FS_TABLE_ROW, float, FS_F32) FS_LIST_TABLE(FS_TABLE_ROW, float, FS_F32)
                           FS_LIST_IRREGULAR(FS_TABLE_ROW) FS_LIST_NODIAG(FS_TABLE_ROW_NODIAG) FS_LIST_LONG(FS_TABLE_ROW_LONG)
-                          FS_LIST_TAIL(FS_TABLE_ROW_TAIL)};
+                          FS_LIST_TAIL(FS_TABLE_ROW_TAIL) FS_LIST_TEAM(FS_TABLE_ROW_TEAM)};
 #endif
 
 // usk / dsk: boundary kinds of the batch.  FS_KERNEL_SHAPE="M,W" and FS_KERNEL_GENERAL=1 (environment) narrow the
@@ -150,8 +159,10 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   const bool beyond0 = usk >= FS_BC_STORAGE_CURVE || dsk >= FS_BC_STORAGE_CURVE;      // general storage / host rows: class -1 only
   if (e.dtype != dtype || e.sec != sec) return false;
   // rows of the scalar system: N - 1 cells + the downstream boundary row; a long-reach kernel makes up to 64 / W passes
-  const long cap = 64L * e.W * e.M * (e.longk ? 64 / e.W : 1);
-  if (cap < N) return false;
+  const long cap = 64L * e.W * e.M * ((e.longk || e.team) ? 64 / e.W : 1);
+  if (cap < N || N > 32768) return false;
+  if (e.team && (N <= 4096 || N <= 64L * e.W * e.M || std::getenv("FS_NO_TEAM"))) return false;      // a team only where one workgroup does not hold the reach (FS_NO_TEAM=1: the multi-pass kernel instead)
+  if (e.team) { if (const char *tm = std::getenv("FS_TEAM_M")) { if (std::atoi(tm) != e.M) return false; } }      // experiments: rows per lane of the team kernel
   if (e.longk && ((need_any && e.bck != -1) || (e.bck == 0 && beyond0))) return false;      // iteration budget / host rows: class -1 (tables, polylines)
   if (e.full && N != cap) return false;
   if (!e.diag && need_diag) return false;
@@ -183,8 +194,10 @@ const Entry *pick_kernel(int dtype, int sec, int N, int usk, int dsk, bool need_
     // smallest capacity first; on ties prefer fewer waves per reach, then the more specific variant
     auto rank = [](const Entry &x) { return x.full + (x.bck >= 2 ? 4 : x.bck == 1 ? 2 : x.bck == 0 ? 1 : 0) + (x.diag ? 0 : 8) + (x.tail >= 0 ? 16 : 0); };
     const int spec = rank(e), bspec = best ? rank(*best) : 0;
-    if (best && e.longk != best->longk) {      // a kernel that keeps the reach on chip whenever one fits
-      if (!e.longk) best = &e;
+    // a kernel that keeps the reach on chip whenever one fits: one workgroup, else a team of them, else the multi-pass kernel
+    const int tier = e.longk ? 2 : (e.team ? 1 : 0), btier = best ? (best->longk ? 2 : (best->team ? 1 : 0)) : 0;
+    if (best && tier != btier) {
+      if (tier < btier) best = &e;
       continue;
     }
     if (!best || e.M * e.W < best->M * best->W || (e.M * e.W == best->M * best->W && e.W < best->W) ||
@@ -336,6 +349,10 @@ struct fs_batch {
   void *kc_scratch = nullptr;          // long reaches: level constants [B][4][passes * 64 W M]
   size_t kc_scratch_elems = 0;
   int passes = 0;
+  void *team_mail = nullptr;           // reaches stepped by teams of workgroups: mailboxes [B][2][G W + 1][kTeamWords]
+  size_t team_mail_elems = 0;
+  unsigned long long *team_sync = nullptr;      // [1 + B] ticket counter + per-reach post counters, zeroed before every launch
+  int team_size = 0;
 };
 
 namespace {
@@ -496,6 +513,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
   a.dbg = b->dbg;
   a.kc_scratch = (R *)b->kc_scratch; a.passes = b->passes;
+  a.team_size = b->team_size; a.team_mail = (R *)b->team_mail; a.team_sync = b->team_sync;
   a.iter_budget = 0; a.it_done = b->it_done;
 }
 
@@ -523,6 +541,19 @@ int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
       HIP_TRY(hipMalloc(&b->kc_scratch, need * b->esz));
       b->kc_scratch_elems = need;
     }
+  }
+  b->team_size = 0;
+  if (k->team) {       // G workgroups per reach: their mailboxes and counters (the counters start every launch at zero)
+    const size_t chunk = (size_t)64 * k->W * k->M, B = b->d.n_reaches;
+    b->team_size = (int)((b->d.n_nodes + chunk - 1) / chunk);
+    const size_t need = B * 2 * ((size_t)b->team_size * k->W + 1) * fs::kTeamWords;
+    if (b->team_mail_elems < need) {
+      if (b->team_mail) { (void)hipFree(b->team_mail); b->team_mail = nullptr; b->team_mail_elems = 0; }
+      HIP_TRY(hipMalloc(&b->team_mail, need * b->esz));
+      b->team_mail_elems = need;
+    }
+    if (!b->team_sync) HIP_TRY(hipMalloc((void **)&b->team_sync, (1 + B) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(b->team_sync, 0, (1 + B) * sizeof(unsigned long long), b->stream));
   }
   HIP_TRY(hipEventRecord(b->ev0, b->stream));
   if (b->d.dtype == FS_F64) {
@@ -634,7 +665,7 @@ void fs_batch_destroy(fs_batch *b) {
   void *bufs[] = {b->hk, b->Qk, b->hg, b->Qg, b->geo_uniform, b->geo_table, b->n_override, b->bc_params[0],
                   b->bc_params[1], b->bc_target[0], b->bc_target[1], b->Yprev, b->stage_hist, b->trace, b->hydro, b->hist_h, b->hist_Q,
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
-                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->ends_dev, b->open_dev};
+                  b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->ends_dev, b->open_dev, b->team_mail, b->team_sync};
   for (void *p : bufs) if (p) (void)hipFree(p);
   if (b->ends_pin) (void)hipHostFree(b->ends_pin);
   if (b->open_pin) (void)hipHostFree(b->open_pin);
@@ -1370,6 +1401,7 @@ int fs_kernel_table_entry(int32_t i, int32_t *out) {
 int32_t fs_batch_kernel_index(fs_batch *b) { return (b && b->kern) ? (int32_t)(b->kern - kEntries) : -1; }
 
 int32_t fs_kernel_table_entry_tail(int32_t i) { return (i >= 0 && i < kNumEntries) ? kEntries[i].tail : -2; }
+int32_t fs_kernel_table_entry_team(int32_t i) { return (i >= 0 && i < kNumEntries) ? kEntries[i].team : -2; }
 
 int32_t fs_batch_poly_tables(fs_batch *b) { return (b && b->poly_x) ? (b->poly_K > 0 ? 1 : 0) : -1; }
 

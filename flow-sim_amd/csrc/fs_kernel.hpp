@@ -218,9 +218,24 @@ template <typename R> struct KernelArgs {
   int32_t poly_K;                // IRREGULAR: P, intervals per node in the stage tables (0: no tables, walk the edges)
   R *kc_scratch;           // long reaches (fs_long.hpp): [B][4][passes * 64 W M] level constants, owned by the batch
   int32_t passes;          // long reaches: passes of 64 W M rows a workgroup makes over its reach
+  // ---- round 4: a reach longer than one lane grid as a TEAM of workgroups (kTeam below) ----
+  int32_t team_size;             // G: workgroups per reach, member g owns rows [g C, (g + 1) C), C = 64 W M
+  R *team_mail;                  // [B][2][G W + 1][kTeamWords] mailboxes: one slot per (member, wave) + one for the upstream row, per iteration parity
+  unsigned long long *team_sync; // [1 + B]: [0] the ticket counter of the launch, [1 + reach] posts made for that reach so far (zeroed before every launch)
 };
+constexpr int kTeamSlots = 64;   // (member, wave) segments of a team: the top tree is one wave wide
+constexpr int kTeamWords = 12;   // per slot: the segment (8), the wave's residual sum (1), two ints (monitor word, boundary flag), pad
 
 template <typename R, int SEC> struct Geometry;
+
+// A team's mailbox (kTeam in the step kernel): every word is written and read with agent-scope atomic accesses - device-coherent
+// stores and loads (sc1), no cache involved that another XCD could not see - so that the exchange needs neither the write-back of
+// the L2 that an agent-scope release costs nor the invalidation of an acquire, both whole-cache operations and both on the critical
+// path of every Newton iteration of every team (measured: the exchange took 22 600 ticks of a 43 000-tick iteration with them).
+// Order is kept the plain way: the poster waits for its stores to be acknowledged (vmcnt) before the workgroup's barrier, thread 0
+// bumps the reach's counter after it; a reader polls the counter, passes a barrier, and only then issues its loads.
+template <typename T> __device__ __forceinline__ void team_put(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void team_posted() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // the descriptor with its kind pinned to what the instantiation was compiled for (BCK >= 2)
 template <int BCK, int SIDE, typename R>
@@ -440,7 +455,16 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
 template <typename R, int M, int T, bool SAVE> struct SavedTerms { R nt[3][M + 1][T]; };
 template <typename R, int M, int T> struct SavedTerms<R, M, T, false> {};
 
-template <typename R, int M, int W, bool SAVE> struct Smem : SavedTerms<R, M, 64 * W, SAVE> {
+// what a team member needs on top (kTeam): the records of the top tree over the team's (member, wave) segments and its results
+template <typename R, bool TEAM> struct TeamSmem {
+  R xtree[4][64];          // records of the top tree (wave 0 of every member computes it, redundantly)
+  R xres[kTeamSlots][4];   // per (member, wave): p of its first row, m of its last row, m of its first row, m of the next one's first row
+  R xtot;
+  int32_t xwarn, xflagT, xstall, xjob;
+};
+template <typename R> struct TeamSmem<R, false> {};
+
+template <typename R, int M, int W, bool SAVE, bool TEAM = false> struct Smem : SavedTerms<R, M, 64 * W, SAVE>, TeamSmem<R, TEAM> {
   static constexpr int T = 64 * W;
   R kc[4][M][T];           // per-cell level-k constants, lane-minor (conflict-free ds_read_b64)
   R tree[W][4][64];        // per-wave records of the in-wave tree (Elim: 4 numbers per merge, 63 merges)
@@ -460,7 +484,11 @@ template <typename R> struct LocalElim { Parked<R> R1, R2, R3, qc; };
 // Minimum number of waves per SIMD a kernel is compiled for: caps its registers at 512 / n.  One wave per SIMD cannot
 // hide the latency of the in-wave tree, a second one is worth 20-80 % wherever the kernel fits 256 registers or nearly
 // does; forcing it on the larger kernels sends them to scratch (measured 0.25-0.8x).
-template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() {
+#ifndef FS_TEAM_WPE
+#define FS_TEAM_WPE 2      // team kernels with <= 8 rows per lane: two workgroups per CU (one computes while the other waits for its team)
+#endif
+template <typename R, int SEC, int M, int W, int BCK, bool TEAM = false> constexpr int min_waves() {
+  if (TEAM && M <= 8 && sizeof(R) == 8) return FS_TEAM_WPE;
   if (W > 1) return 1;          // multi-wave table kernels with 2 cells per lane at two waves per SIMD: no better than the 4- and 8-cell ones
   if (sizeof(R) == 4) return (M <= 8 && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM)) ? FS_WPE_W1_F32_UNIFORM : FS_WPE_W1_F32;
   if (SEC == FS_SEC_RECT_UNIFORM && BCK >= 1 && M <= 8) return FS_WPE_RECT8;
@@ -483,10 +511,24 @@ template <typename R, int SEC, int M, int W, int BCK> constexpr int min_waves() 
 // cells of clamped, frozen copies of node N - 1 ("phantom" cells: finite, diagonally dominant, and behind a boundary row whose
 // super-diagonal is zero, so nothing upstream of it ever reads them - the real unknowns get the very bits of the ragged kernel);
 // two lane masks hoisted out of the time loop keep the phantom rows out of the residual norm and the phantom nodes where they are.
-template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true, int TAIL = -1>
-__global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void preissmann_step_kernel(const KernelArgs<R> a) {
+// TEAM (round 4): a reach LONGER than one lane grid (N > 64 W M rows) advanced by a team of G = a.team_size workgroups, each holding
+// C = 64 W M rows of it on chip exactly as a short reach is held - unknowns in registers, level constants in LDS, HBM read once per
+// launch and written once - where the multi-pass kernel (fs_long.hpp) streams the Newton vector through memory twice per iteration.
+// What the W waves of one workgroup exchange through LDS (step 4) the G W waves of a team exchange through a mailbox in device
+// memory: every wave posts its segment, one release / acquire pair on a per-reach counter (agent scope) stands where the barrier
+// stood, wave 0 of every member reduces the G W segments with one more DPP tree (the multi-pass kernel's top tree: identity segments
+// pad the 64 lanes), closes the root with the upstream row and hands every wave its four numbers back through LDS.  All members
+// see the same numbers and take the same decisions (convergence, failure, monitor), so the time loop needs no other exchange.
+// Membership is by TICKET, not by blockIdx: a workgroup takes the next (reach, member) job when it starts, so the members of the
+// oldest unfinished team are exactly the workgroups that started first - all resident, whatever order the dispatcher chose and
+// whatever else runs on the device; a team therefore never waits for a workgroup that cannot start (no co-residency assumption
+// beyond G <= CUs).  A wait that still exceeds ~2 s of s_memtime ends the reach with FS_TEAM_STALL instead of spinning on.
+template <typename R, int SEC, int M, int W, bool RAGGED = true, int BCK = 0, bool DIAG = true, int TAIL = -1, bool TEAM = false>
+__global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) void preissmann_step_kernel(const KernelArgs<R> a) {
   static_assert(M >= 2, "a lane's segment needs two rows (its up and its down row)");
   constexpr bool kTail = TAIL >= 0;
+  constexpr bool kTeam = TEAM;
+  static_assert(!kTeam || (RAGGED && W > 1 && (BCK == 0 || BCK == 1) && !kTail), "team form: the general ragged multi-wave kernels");
   static_assert(!kTail || (RAGGED && W == 1 && TAIL < M && SEC == FS_SEC_TABLE && BCK >= 2), "tail-only form: ragged one-wave table kernels compiled for a boundary pair");
   constexpr int T = 64 * W;
   using Geo = Geometry<R, SEC>;
@@ -496,10 +538,18 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   constexpr bool kRegGeo = FS_REG_GEO && SEC == FS_SEC_TABLE && W == 1 && M <= 2;
   constexpr bool kFlatBC = FS_FLAT_BC && BCK >= 2 && sizeof(R) == 8 && SEC == FS_SEC_TRAP_UNIFORM;   // measured: C5 fp64 +1.5 %; flagship -1.5 %, C4 -7 %, polyline -1.3 %
   constexpr bool kSaveTerms = FS_SAVE_TERMS && !Geometry<R, SEC>::kConstT && (M <= 2 || (sizeof(R) == 8 && M <= FS_SAVE_TERMS_MAXM_F64));
-  __shared__ Smem<R, M, W, kSaveTerms> sm;
+  __shared__ Smem<R, M, W, kSaveTerms, kTeam> sm;
 
-  const int reach = blockIdx.x;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int job = blockIdx.x;
+  if constexpr (kTeam) {      // the next job in order of ARRIVAL (see above)
+    if (t == 0) sm.xjob = (int)__hip_atomic_fetch_add(a.team_sync, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    job = sm.xjob;
+  }
+  const int G = kTeam ? a.team_size : 1;
+  const int reach = kTeam ? job / G : job, member = kTeam ? job - reach * G : 0;
+  const int gt = member * T + t;                 // the lane's place in the reach's lane grid (t itself unless the reach is a team's)
   // One Newton iteration per launch for batches with host-evaluated boundary rows (FS_BC_HOST_ROW, fs_batch_iterate): the
   // kernels of boundary class -1 carry an iteration budget and the count of the open level across launches.
   constexpr bool kBudget = (BCK == -1);
@@ -511,11 +561,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   // nodes of this reach; NS = a.N stays the row stride of every [B][N] array (heterogeneous batches: RAGGED kernels only)
   const int NS = a.N;
   const int N = (RAGGED && a.reach_nodes) ? a.reach_nodes[reach] : a.N, NC = N - 1;
-  const int s0 = t * M;                       // first node / row of this lane
-  const int tD = RAGGED ? NC / M : T - 1;     // lane that owns node N-1 and the downstream boundary row ...
+  const int s0 = gt * M;                      // first node / row of this lane
+  const int tD = RAGGED ? NC / M : T - 1;     // lane (of the reach's lane grid: gt) that owns node N-1 and the downstream boundary row ...
   const int jD = kTail ? TAIL : (RAGGED ? NC - tD * M : M - 1);   // ... as its local node / row jD (0..M-1; tail-only form: fs_abi.hip picks the instantiation with TAIL = NC mod M)
   // tail-only form: 1.0 in the lanes up to / before the one that owns node N - 1, else 0.0 (multiplied in, never selected on)
-  const R mle = (kTail && t > tD) ? R(0) : R(1), mlt = (kTail && t >= tD) ? R(0) : R(1);
+  const R mle = (kTail && gt > tD) ? R(0) : R(1), mlt = (kTail && gt >= tD) ? R(0) : R(1);
   const size_t base = (size_t)reach * NS;
 
   Geo geo;
@@ -675,7 +725,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   }
   // a compile-time constant in the kernels compiled for a boundary pair
   const bool ds_storage = BCK >= 2 ? bc_is_storage(BCK - 2) : bc_is_storage(dsd.kind);
-  R Yprev = (ds_storage && t == tD) ? a.Yprev[reach] : R(0);
+  R Yprev = (ds_storage && gt == tD) ? a.Yprev[reach] : R(0);
   int status = a.status[reach];
   // FS_ILL_CONDITIONED is a warning that sticks to the reach, not a failure: the run goes on (and a later launch finds it here)
   constexpr bool kMonitor = DIAG || FS_MONITOR_ALL;
@@ -683,6 +733,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
   if (warn) status = FS_OK;
   bool primed = false;                        // (h, Q) hold the Newton vector (after the priming pass), not the entry state
   int parity = 0;
+  int exchanges = 0;                          // team form: exchanges made in this launch (the reach's counter stands at exchanges G after each)
   if (t == 0) { sm.xflag[0] = 0; sm.xflag[1] = 0; }
   __syncthreads();
 
@@ -693,7 +744,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       const int node = min(s0 + j, N - 1);
       hk[j] = a.hk[base + node]; Qk[j] = a.Qk[base + node];
     }
-    if (t == tD) {
+    if (gt == tD) {
 #pragma unroll
       for (int j = RAGGED ? 0 : M - 1; j < M; ++j) if (j == jD) QoldD = Qk[j];
     }
@@ -758,6 +809,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       BCRow<R> Urow, Drow;
       Drow.dh = R(1); Drow.dq = R(0); Drow.res = R(0);
       R nrm2 = R(0);
+      int myflag = 0;                          // team form: the flag a storage row raised in this lane (the only value: FS_STORAGE_RANGE)
       if constexpr (kFlatBC) {
         // Boundary kinds fixed at compile time: EVERY lane evaluates both rows, on its own numbers, as straight-line code;
         // only lane 0 / the lane of node N-1 keep what comes out.  A wave executes a divergent branch for one lane at the
@@ -771,19 +823,19 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 #pragma unroll
         for (int j = RAGGED ? 1 : M - 1; j < M; ++j) if (j == jD) { hD = h[j]; QD = Q[j]; }
         Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &YnewAll, &fD);
-        const bool isD = t == tD;
-        nrm2 = (t == 0 ? Urow.res * Urow.res : R(0)) + (isD ? Drow.res * Drow.res : R(0));
+        const bool isD = gt == tD;
+        nrm2 = (gt == 0 ? Urow.res * Urow.res : R(0)) + (isD ? Drow.res * Drow.res : R(0));
         if (isD) {
           Ynew = YnewAll;
           if (fD) sm.xflag[parity] = fD;
         }
       } else {
-        if (t == 0) {
+        if (gt == 0) {
           R dummy; int flag = 0;
           Urow = geo.template boundary<BCK, 0>(usd, reach, a.B, level, 0, h[0], Q[0], R(0), dt, R(0), &dummy, &flag);
           nrm2 = Urow.res * Urow.res;
         }
-        if (t == tD && !fuseD) {
+        if (gt == tD && !fuseD) {
           R hD = h[0], QD = Q[0];
           int flag = 0;
 #pragma unroll
@@ -791,6 +843,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           Drow = geo.template boundary<BCK, 1>(dsd, reach, a.B, level, N - 1, hD, QD, QoldD, dt, Yprev, &Ynew, &flag);
           nrm2 += Drow.res * Drow.res;
           if (flag) sm.xflag[parity] = flag;
+          if (kTeam && flag) myflag = flag;
         }
       }
       FS_T(1);
@@ -809,9 +862,14 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
         save_terms(0, L);
         R i2tL = dt * L.rT;
         if (!Geo::kConstT) iTn[0] = i2tL;
-        if (t == 0) {                           // upstream row on (p_0, m_0): aU p_0 + bU m_0 = -res
+        if (gt == 0) {                          // upstream row on (p_0, m_0): aU p_0 + bU m_0 = -res
           const R x = Urow.dh * i2tL, y = Urow.dq * i2c;
+          if constexpr (kTeam) {                // (a team's: into the mailbox, next to the segments)
+            R *q = a.team_mail + (((size_t)reach * 2 + parity) * (G * W + 1) + G * W) * kTeamWords;
+            team_put(q + 0, x + y); team_put(q + 1, x - y); team_put(q + 2, -Urow.res);
+          } else {
           sm.xbc[parity][0] = x + y; sm.xbc[parity][1] = x - y; sm.xbc[parity][2] = -Urow.res;
+          }
         }
         R rcPrev = R(0);
 #pragma unroll
@@ -842,7 +900,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
             R r2 = fma_(Cres, Cres, Mres * Mres);
             if constexpr (kTail) {
               if (c == TAIL) {                 // the boundary row, in the one lane that owns node N - 1 (its residual was added in step 1)
-                const bool isD = t == tD;
+                const bool isD = gt == tD;
                 const R x = Drow.dh * i2tL, y = Drow.dq * i2c;
                 row.al = isD ? x + y : row.al; row.D = isD ? x - y : row.D; row.de = isD ? R(0) : row.de;
                 row.rho0 = isD ? -Drow.res : row.rho0; row.rc = isD ? R(0) : row.rc;
@@ -852,7 +910,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
             // rows beyond the cells: the downstream boundary row (on p and m of node N-1), then identity rows
             if (RAGGED || c == M - 1) {
               const int k = s0 + c;
-              const bool cell = RAGGED ? (k < NC) : (t != T - 1);
+              const bool cell = RAGGED ? (k < NC) : (t != T - 1);      // (k = s0 + c counts along the whole reach)
               const bool bcr = RAGGED ? (k == NC) : true;
               if (!cell) {
                 BCRow<R> Dr = Drow;
@@ -929,6 +987,17 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       __builtin_amdgcn_sched_barrier(0);
 #endif
       nrm2 = wave_sum(nrm2);
+      if constexpr (kTeam) {
+        const int wflag = __builtin_amdgcn_ballot_w64(myflag != 0) != 0 ? (int)FS_STORAGE_RANGE : 0;      // raised by a lane of this wave
+        if (lane == 63) {                    // the wave's slot of the team's mailbox (device memory; published by the release below)
+          R *p = a.team_mail + (((size_t)reach * 2 + parity) * (G * W + 1) + (member * W + wave)) * kTeamWords;
+          team_put(p + 0, seg.u1); team_put(p + 1, seg.u3); team_put(p + 2, seg.ru); team_put(p + 3, seg.d1); team_put(p + 4, seg.d2);
+          team_put(p + 5, seg.d3); team_put(p + 6, seg.rd); team_put(p + 7, seg.rc); team_put(p + 8, nrm2);
+          int32_t *pi = reinterpret_cast<int32_t *>(p + 9);
+          team_put(pi, gi); team_put(pi + 1, wflag);
+        }
+        team_posted();
+      } else
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
         p[0] = seg.u1; p[1] = seg.u3; p[2] = seg.ru; p[3] = seg.d1; p[4] = seg.d2; p[5] = seg.d3; p[6] = seg.rd; p[7] = seg.rc;
@@ -974,7 +1043,103 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       R tot = R(0);
       R pL, mR;                        // p of this wave's first row, m of its last one
       R mAw = R(0), mBw = R(0);        // m of this wave's first row / of the next wave's first row (shared nodes, below)
-      if constexpr (W > 1 && W >= FS_XLANES_MINW) {
+      if constexpr (kTeam) {
+        // ---- the team's exchange: where one workgroup has a barrier, G workgroups have a counter in device memory ----
+        // (every poster has seen its stores acknowledged before the __syncthreads above, thread 0 counts the workgroup in after it; the
+        // counter of a reach only grows: the e-th exchange of the launch is complete when it reaches e G)
+        ++exchanges;
+        if (t == 0) {
+          unsigned long long *cnt = a.team_sync + 1 + reach;
+          __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long want = (unsigned long long)exchanges * (unsigned long long)G;
+          const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+          int stall = 0;
+          // (relaxed polls: an acquire per poll would invalidate the caches of the whole XCD on every turn; one acquire fence follows the wait)
+          while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memtime() - t_in > 4000000000ull) { stall = 1; break; }     // ~2 s of s_memtime: give the reach up, do not spin on
+          }
+          sm.xstall = stall;
+        }
+        FS_T(11);
+        __syncthreads();
+        if (wave == 0) {
+          // the top tree over the S = G W posted segments, one per lane, identity segments beyond (the multi-pass kernel's, fs_long.hpp)
+          const int S = G * W;
+          const R *mail = a.team_mail + ((size_t)reach * 2 + parity) * (S + 1) * kTeamWords;
+          const R *q = mail + (size_t)(lane < S ? lane : 0) * kTeamWords;
+          auto ld = [&](int i) { return __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+          Seg<R> xs;
+          xs.u1 = ld(0); xs.u3 = ld(1); xs.ru = ld(2); xs.d1 = ld(3); xs.d2 = ld(4); xs.d3 = ld(5); xs.rd = ld(6); xs.rc = ld(7);
+          R nr = ld(8);
+          const int32_t *qi = reinterpret_cast<const int32_t *>(q + 9);
+          int gx = __hip_atomic_load(qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          int fl = __hip_atomic_load(qi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lane >= S) { xs.u1 = R(0); xs.u3 = R(0); xs.ru = R(0); xs.d1 = R(0); xs.d2 = R(1); xs.d3 = R(0); xs.rd = R(0); xs.rc = R(0); nr = R(0); gx = 0; fl = 0; }
+          const R aU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const R bU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const R rU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const R u1o = xs.u1, u3o = xs.u3, ruo = xs.ru;
+          auto xup = [&](auto lc) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;
+            constexpr int d = 1 << l;
+            const Seg<R> left = seg_from_below<d>(xs);
+            Seg<R> mg; Elim<R> e;
+            merge(left, xs, mg, e);
+            if ((lane & (2 * d - 1)) == (2 * d - 1)) {
+              R *w = &sm.xtree[0][(64 - (64 >> l)) + (lane >> (l + 1))];
+              w[0 * 64] = e.A1; w[1 * 64] = e.A2; w[2 * 64] = e.A3; w[3 * 64] = e.rc;
+            }
+            xs = mg;
+            gx = max_(max_(tree_from_below<d>(gx), gx), hi_abs(mg.u3));
+            fl = max_(tree_from_below<d>(fl), fl);
+          };
+          // (levels that would only merge identity segments are skipped: S <= 2^nl lanes carry something; the root then sits in lane 2^nl - 1)
+          const int nl = S <= 8 ? 3 : (S <= 16 ? 4 : (S <= 32 ? 5 : 6));
+          xup(std::integral_constant<int, 0>{}); xup(std::integral_constant<int, 1>{}); xup(std::integral_constant<int, 2>{});
+          if (nl > 3) xup(std::integral_constant<int, 3>{});
+          if (nl > 4) xup(std::integral_constant<int, 4>{});
+          if (nl > 5) xup(std::integral_constant<int, 5>{});
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          R p0, m0, ml;
+          close_root(xs, aU, bU, rU, p0, m0, ml);            // valid in the root's lane
+          const int rl = (1 << nl) - 1;
+          R px = read_lane(p0, rl), mx = read_lane(ml, rl);
+          auto xdown = [&](auto lc) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;
+            const R *w = &sm.xtree[0][(64 - (64 >> l)) + (lane >> (l + 1))];
+            Elim<R> e;
+            e.A1 = w[0 * 64]; e.A2 = w[1 * 64]; e.A3 = w[2 * 64]; e.rc = w[3 * 64];
+            const R sep = separator(e, px, mx);
+            const bool upper = ((lane >> l) & 1) != 0;
+            px = upper ? e.rc - sep : px;
+            mx = upper ? mx : sep;
+          };
+          if (nl > 5) xdown(std::integral_constant<int, 5>{});
+          if (nl > 4) xdown(std::integral_constant<int, 4>{});
+          if (nl > 3) xdown(std::integral_constant<int, 3>{});
+          xdown(std::integral_constant<int, 2>{}); xdown(std::integral_constant<int, 1>{}); xdown(std::integral_constant<int, 0>{});
+          const R ma = fma_(-u1o, px, fma_(-u3o, mx, ruo));
+          R mb = dpp_mov<0x134>(ma);                // wave_rol:1 : m of the next segment's first row
+          if (lane == 63) mb = R(0);
+          if (lane < S) { R *o = sm.xres[lane]; o[0] = px; o[1] = mx; o[2] = ma; o[3] = (lane == S - 1) ? R(0) : mb; }
+          const R tsum = wave_sum(nr);               // (a fixed order: the same total in every member)
+          // (cross-lane reads in uniform control flow, fs_long.hpp)
+          const int gtop = __builtin_amdgcn_readlane(gx, rl), ftop = __builtin_amdgcn_readlane(fl, rl);
+          if (lane == 0) { sm.xtot = tsum; sm.xwarn = gtop > growth_limit_bits<R>() ? 1 : 0; sm.xflagT = ftop; }
+        }
+        __syncthreads();
+        tot = sm.xtot;
+        {
+          const R *xr = sm.xres[member * W + wave];
+          pL = xr[0]; mR = xr[1]; mAw = xr[2]; mBw = xr[3];
+        }
+        if constexpr (kMonitor) { if (sm.xwarn != 0) grow = true; }
+        if (sm.xflagT != 0) status = sm.xflagT;
+        if (sm.xstall != 0) status = FS_TEAM_STALL;
+      } else if constexpr (W > 1 && W >= FS_XLANES_MINW) {
         // A second, small tree over the W wave segments, one segment per LANE: lane w of every wave takes the segment of
         // wave w and the W - 1 merges run as log2 W DPP levels (row_shr:1/2/4) exactly like the in-wave tree - the same
         // merges in the same order as the per-thread fold below, so the bits do not change - with 8 live numbers per lane
@@ -1154,7 +1319,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       __builtin_amdgcn_sched_barrier(0);
 #endif
       FS_T(4);
-      if ((BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag
+      if (!kTeam && (BCK < 2 || ds_storage) && sm.xflag[parity] != 0) status = sm.xflag[parity];     // only the storage rows raise a flag (a team's: through the mailbox, above)
       // ||R|| = sqrt(tot) (utility.py:20-22) is NaN or beyond the blow-up bound (preissmann.py:135-137) exactly when tot is
       // not finite (the bound exceeds the root of the largest finite number in either precision)
       if (!(tot <= finite_max<R>())) status = FS_NAN;
@@ -1162,7 +1327,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       if (DIAG || M < 8) {               // (the two-rows-per-lane kernels sit on their register cap: the branch below costs C4 19 %)
         const R err = sqrt_(tot);
         below = err < a.tol;
-        if (DIAG && a.trace && t == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
+        if (DIAG && a.trace && gt == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
       } else {
         // without a trace to write the root is only needed when tot lies within rounding of tol^2 (the decision must be
         // the one sqrt() gives, bit for bit: Newton counts are compared with the reference's)
@@ -1308,7 +1473,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
 
       // ================= 6. accepted iterate -> level k =================
       if (converged) {
-        if (!prime && t == 0) {
+        if (!prime && gt == 0) {
           a.hydro[((size_t)level * 4 + 0) * a.B + reach] = h[0];
           a.hydro[((size_t)level * 4 + 1) * a.B + reach] = Q[0];
           a.iters[(size_t)level * a.B + reach] = it;
@@ -1332,7 +1497,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
           }
         }
         FS_T(8);
-        if (t == tD) {
+        if (gt == tD) {
 #pragma unroll
           for (int j = RAGGED ? 0 : M - 1; j < M; ++j)
             if (j == jD) {
@@ -1376,7 +1541,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
       }
     }
     if (prime) continue;
-    if (status != FS_OK && t == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
+    if (status != FS_OK && gt == 0) a.iters[(size_t)level * a.B + reach] = it - (status == FS_MAX_ITER ? 1 : 0);
     if (kBudget && a.iter_budget > 0) {
       if (t == 0) a.it_done[reach] = (converged || status != FS_OK) ? -1 : it;
       if (!converged) break;                  // budget spent: the Newton vector goes back to hg / Qg below
@@ -1389,11 +1554,11 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK>())) void prei
     for (int j = 0; j < M; ++j)
       if (!RAGGED || s0 + j < N) { hg_p[j] = h[j]; Qg_p[j] = Q[j]; }
   }
-  if (t == 0) a.status[reach] = (status == FS_OK && warn) ? (int)FS_ILL_CONDITIONED : status;
-  if (ds_storage && t == tD) a.Yprev[reach] = Yprev;
+  if (gt == 0) a.status[reach] = (status == FS_OK && warn) ? (int)FS_ILL_CONDITIONED : status;
+  if (ds_storage && gt == tD) a.Yprev[reach] = Yprev;
 #ifdef FS_STAMP
   if (a.dbg && lane == 0)
-    for (int i = 0; i < 12; ++i) a.dbg[((size_t)reach * 16 + wave) * 12 + i] = stamp_[i];
+    for (int i = 0; i < 12; ++i) a.dbg[((size_t)reach * 16 + (member * W + wave) % 16) * 12 + i] = stamp_[i];
 #endif
 }
 

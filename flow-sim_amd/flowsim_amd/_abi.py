@@ -24,7 +24,7 @@ GEO_NPARAM = len(GEO_ROWS)
 SC_NAMES = ("min_stage", "Y_min", "Y_max", "bed_level", "surface_area", "alpha", "beta", "n_curve", "rc_type", "rc_a",
             "rc_b", "rc_c", "rc_shift", "capture_losses", "reservoir_length", "K_q")
 UPSTREAM, DOWNSTREAM = 0, 1
-OK, MAX_ITER, NAN, STORAGE_RANGE, ILL_CONDITIONED = 0, 1, 2, 3, 4
+OK, MAX_ITER, NAN, STORAGE_RANGE, ILL_CONDITIONED, TEAM_STALL = 0, 1, 2, 3, 4, 5
 FLAG_HISTORY, FLAG_TRACE, FLAG_MONITOR = 1, 2, 4
 TRACE_CAP = 64
 DERIVE_ALL = 255
@@ -89,6 +89,7 @@ SIGNATURES = {
     "fs_batch_kernel_index": (C.c_int32, [_P]),
     "fs_batch_poly_tables": (C.c_int32, [_P]),
     "fs_kernel_table_entry_tail": (C.c_int32, [C.c_int32]),
+    "fs_kernel_table_entry_team": (C.c_int32, [C.c_int32]),
 }
 
 _lib = None
@@ -140,5 +141,5 @@ def kernel_table():
     for i in range(l.fs_kernel_table_size()):
         v = (C.c_int32 * 8)()
         check(l.fs_kernel_table_entry(i, v), "kernel_table")
-        out.append(dict(zip(KERNEL_FIELDS, (int(x) for x in v)), index=i, tail=int(l.fs_kernel_table_entry_tail(i))))
+        out.append(dict(zip(KERNEL_FIELDS, (int(x) for x in v)), index=i, tail=int(l.fs_kernel_table_entry_tail(i)), team=int(l.fs_kernel_table_entry_team(i))))
     return out

@@ -127,6 +127,8 @@ class PreissmannSolver(Solver):
                 raise ValueError(f'Convergence within {max_iter} iterations couldn\'t be achieved.')
             if status == A.STORAGE_RANGE:
                 raise ValueError("f(a) and f(b) must have different signs")      # what brentq raises in the reference
+            if status == A.TEAM_STALL:
+                raise RuntimeError("device: a workgroup of this reach's team did not arrive (FS_TEAM_STALL, include/flowsim_abi.h)")
             raise ValueError("NaN in system assembly")
         self.time_level = nt - 1
         self.depth[:], self.flow[:] = h[:nt, 0], Q[:nt, 0]

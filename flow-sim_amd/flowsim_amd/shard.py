@@ -2,8 +2,9 @@
 
 Reaches / ensemble members are independent: each rank owns a contiguous
 block of global reach indices and steps it without talking to anyone.  The only exchange is the
-gather of the boundary hydrographs [levels, 4, B_local] - an all_gather over RCCL (backend
-"nccl" on ROCm) or gloo (CPU tests)."""
+gather of the boundary hydrographs [levels, 4, B_local] over RCCL (backend "nccl" on ROCm) or gloo (CPU tests): to one
+root rank (what north_star asks for: every other rank sends its block straight to the root, one xGMI hop, 1/world of the bytes
+an all_gather moves through every rank) or, with root=None, to every rank."""
 import torch
 import torch.distributed as dist
 
@@ -21,20 +22,28 @@ def split_reaches(total: int, rank: int, world: int):
     return first, count
 
 
-def gather_hydrographs(local: torch.Tensor, world: int) -> torch.Tensor:
-    """local [levels, 4, B] on every rank -> [levels, 4, world*B] in global reach order (all ranks)."""
+def gather_hydrographs(local: torch.Tensor, world: int, root=None):
+    """local [levels, 4, B] on every rank -> [levels, 4, world*B] in global reach order: on every rank (root=None, an
+    all_gather) or on rank `root` alone (a gather: the other ranks return None)."""
     if world == 1:
         return local
     local = local.contiguous()
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local)
+    if root is None:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out.view(world * local.shape[0], *local.shape[1:]), local)
+    else:
+        me = dist.get_rank()
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device) if me == root else None
+        dist.gather(local, list(out.unbind(0)) if me == root else None, dst=root)
+        if me != root:
+            return None
     return out.permute(1, 2, 0, 3).reshape(local.shape[0], local.shape[1], world * local.shape[2])
 
 
-def gather_hydrographs_split(local: torch.Tensor, total: int, world: int) -> torch.Tensor:
+def gather_hydrographs_split(local: torch.Tensor, total: int, world: int, root=None):
     """The same gather for the strong-scaling layout (split_reaches): the blocks differ by at most one reach, the
     shorter ones travel padded by a column (all_gather wants equal shapes) that is dropped again on arrival.
-    local [levels, 4, count(rank)] -> [levels, 4, total] in global reach order (all ranks)."""
+    local [levels, 4, count(rank)] -> [levels, 4, total] in global reach order (all ranks, or `root` alone: see gather_hydrographs)."""
     if world == 1:
         return local
     counts = [split_reaches(total, r, world)[1] for r in range(world)]
@@ -43,8 +52,8 @@ def gather_hydrographs_split(local: torch.Tensor, total: int, world: int) -> tor
         padded = torch.zeros(local.shape[:2] + (widest,), dtype=local.dtype, device=local.device)
         padded[:, :, :local.shape[2]] = local
         local = padded
-    out = gather_hydrographs(local, world)
-    if min(counts) == widest:
+    out = gather_hydrographs(local, world, root)
+    if out is None or min(counts) == widest:
         return out
     keep = torch.cat([torch.arange(r * widest, r * widest + c, device=out.device) for r, c in enumerate(counts)])
     return out.index_select(2, keep)

@@ -122,7 +122,13 @@ enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3,
         * `diagnos` check of run(), ValueError("Jacobian is ill-conditioned (rcond too small)"), preissmann.py:139-144, and
         * the Froude diagnosis of check_criticality (:179-198).  Raised by the kernels compiled with diagnostics: every batch
         * with FS_FLAG_HISTORY, FS_FLAG_TRACE or FS_FLAG_MONITOR, and every batch no specialised kernel exists for. */
-       FS_ILL_CONDITIONED = 4 };
+       FS_ILL_CONDITIONED = 4,
+       /* A reach longer than one lane grid is advanced by a team of workgroups that meet once per Newton iteration (uniform section
+        * modes beyond 4 096 nodes).  A member that waits for the others longer than about two seconds gives the reach up with this
+        * status instead of spinning on; it has not been seen to happen (a team's members are the workgroups that started first, so
+        * none of them waits for one that cannot start) and would mean a lost or wedged workgroup.  The reach's state is that of the
+        * last launch that completed. */
+       FS_TEAM_STALL = 5 };
 
 enum {
   FS_FLAG_HISTORY = 1,  /* keep depth/flow[level][B][N] on the device (solver.py:43-44); large batches that only need the
@@ -309,6 +315,10 @@ int32_t fs_batch_kernel_index(fs_batch *b);
  * that row, (N - 1) mod M, or -1 for every other entry (-2: no such entry).  fs_batch_step only picks such an entry for a batch
  * whose one node count gives that row. */
 int32_t fs_kernel_table_entry_tail(int32_t i);
+/* 1: entry i advances a reach LONGER than one lane grid as a team of ceil(N / (64 W M)) workgroups that each keep 64 W M rows on chip and
+ * meet once per Newton iteration through device memory (uniform section modes, 4 097 ... 32 768 nodes; round 4) - fs_batch_step prefers it
+ * to the multi-pass entries (long = 1), which remain for tables, polylines, host rows and FS_NO_TEAM=1; 0 otherwise (-2: no such entry). */
+int32_t fs_kernel_table_entry_team(int32_t i);
 /* FS_SEC_IRREGULAR: 1 when the batch evaluates its polylines from stage tables, 0 when it walks their edges (the same results at
  * about five times the instructions): the tables take about 10 KB per node at 40 stations, per channel, and
  * fs_batch_set_geometry_irregular(_per_reach) leaves them out beyond FS_POLY_TABLE_MAX_BYTES (environment, default 8 GiB) or with

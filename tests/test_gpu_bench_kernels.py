@@ -212,5 +212,5 @@ def test_extra_workloads_of_the_bench_line(spec):
     real = 4 if spec[1] == "f32" else 8
     assert abs(r["achieved"] - spec[2] * spec[4] * (4 * spec[3] * real + 40) / (w["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     k = w["kernel"]
-    want = {"c4": (2, 1, 0), "c5": (8, 1, 0), "irr": (2, 1, 0), "long": (8, 4, 1)}[spec[0]]
-    assert (k["cells_per_thread"], k["waves_per_reach"], k["long_reach"]) == want and (k["diag"] == 0 or k["long_reach"])
+    want = {"c4": (2, 1, 0), "c5": (8, 1, 0), "irr": (2, 1, 0), "long": (16, 4, 1)}[spec[0]]          # long: a team of four workgroups per reach
+    assert (k["cells_per_thread"], k["waves_per_reach"], k["team"]) == want and k["long_reach"] == 0 and (k["diag"] == 0 or k["team"])

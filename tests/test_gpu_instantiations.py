@@ -40,11 +40,13 @@ def _id(e):
     sec = ("rect", "trap", "table", "irr")[e["section_mode"]]
     return (f"{e['index']:03d}-{'f64' if e['dtype'] == 0 else 'f32'}-{sec}-{e['cells_per_thread']}x{e['waves_per_reach']}"
             f"{'-full' if e['full'] else ''}-bc{e['boundary_class']}{'' if e['diag'] else '-nodiag'}{'-long' if e.get('long_reach') else ''}"
-            f"{'-tail%d' % e['tail'] if e.get('tail', -1) >= 0 else ''}")
+            f"{'-tail%d' % e['tail'] if e.get('tail', -1) >= 0 else ''}{'-team' if e.get('team') else ''}")
 
 
 def _nodes(e):
     cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]      # rows of the scalar system: N - 1 cells + the boundary row
+    if e.get("team"):
+        return 2 * cap + cap // 5 + e["index"] % 9            # a team of three workgroups, the last one mostly padding
     if e.get("long_reach"):
         return 2 * cap + cap // 3 + e["index"] % 7            # the multi-pass kernel (fs_long.hpp): three passes, the last one ragged
     if e["full"]:
@@ -191,7 +193,7 @@ def test_instantiation_against_the_oracle(e, monkeypatch):
     f32 = e["dtype"] == A.F32
     if f32:
         p.tol = 1e-3 if p.N <= 600 else 2e-2      # fp32 cannot resolve ||R|| below ~6e-8 |Q| sqrt(2N) (bench.py uses the same)
-    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"] * (64 // e["waves_per_reach"] if e.get("long_reach") else 1)
+    cap = 64 * e["cells_per_thread"] * e["waves_per_reach"] * (64 // e["waves_per_reach"] if (e.get("long_reach") or e.get("team")) else 1)
     assert p.N <= cap, "recipe does not fit the entry"
     ref = oracle_run(p)
     assert ref["status"] == 0

@@ -368,16 +368,23 @@ def test_ragged_node_counts_against_the_c_oracle(N):
 
 
 @pytest.mark.parametrize("N", [4097, 6000, 8192, 16384, 32768])
-@pytest.mark.parametrize("mode", ["rect_uniform", "table", "trap_uniform"])
-def test_reaches_longer_than_the_lane_grid_against_the_c_oracle(N, mode):
+@pytest.mark.parametrize("mode", ["rect_uniform", "table", "trap_uniform", "rect_uniform-multipass", "trap_uniform-multipass"])
+def test_reaches_longer_than_the_lane_grid_against_the_c_oracle(N, mode, monkeypatch):
     """The reference has no limit on the number of nodes (solver.py:34-38, :53-55).  Beyond what one workgroup keeps on chip
-    (4 096 rows for the uniform section modes, 2 048 for tables) the multi-pass kernel of fs_long.hpp takes over: state in
-    HBM / L2, level constants in a scratch of the batch, two sweeps per Newton iteration.  Same bar as everywhere: the pivoted C
-    oracle to 1e-8 with identical Newton counts; three reaches per batch, chunked stepping equal to one launch bit for bit."""
+    (4 096 rows for the uniform section modes, 2 048 for tables): uniform sections - a TEAM of workgroups, each holding 4 096 rows
+    on chip, meeting once per Newton iteration through device memory (fs_kernel.hpp, round 4); tables, and uniform sections with
+    FS_NO_TEAM=1 - the multi-pass kernel of fs_long.hpp (state in HBM / L2, two sweeps per Newton iteration).  Same bar as
+    everywhere: the pivoted C oracle to 1e-8 with identical Newton counts; three reaches per batch, chunked stepping equal to one
+    launch bit for bit."""
     from fixture_batch import batch_from_problems, hetero_batch_from_problems
+    from flowsim_amd import _abi as A_
     from oracle import c_oracle
     from synth import rect_problem
-    if mode != "rect_uniform" and N > 16384:
+    multipass = mode.endswith("-multipass")
+    mode = mode.split("-")[0]
+    if multipass:
+        monkeypatch.setenv("FS_NO_TEAM", "1")
+    if mode == "table" and N > 16384:
         pytest.skip("tables stop at 16 384 nodes")
     probs = [rect_problem(N, seed=900 + N % 97 + s, n_steps=3) for s in range(3)]
     if mode == "trap_uniform":
@@ -389,7 +396,9 @@ def test_reaches_longer_than_the_lane_grid_against_the_c_oracle(N, mode):
         b.step(3)
         assert np.all(b.status() == 0)
         info = b.kernel_info()
-        assert 64 * info["cells_per_thread"] * info["waves_per_reach"] < N         # the multi-pass kernel did run
+        assert 64 * info["cells_per_thread"] * info["waves_per_reach"] < N         # more than one workgroup holds
+        e = A_.kernel_table()[b.kernel_index()]
+        assert (e["team"], e["long_reach"]) == ((0, 1) if (multipass or mode == "table") else (1, 0)), e
         h, Q = b.history_arrays()
         its = b.iterations()
         hyd = b.hydrographs()

@@ -128,3 +128,66 @@ def test_stage_tables_beyond_the_bound_fall_back_to_the_edge_walk(monkeypatch):
     for h, Q, its in res.values():
         assert rel(h[:, 0], fx["depth"][:9], 1e-3) <= TOL and rel(Q[:, 0], fx["flow"][:9], 1.0) <= TOL
         assert np.array_equal(its[:, 0], fx["iters"][:9])
+
+
+def test_a_ragged_batch_of_long_uniform_reaches_on_the_team_kernel():
+    """Reaches of 4 097 ... 16 384 nodes in ONE rectangular batch (per-reach node counts): every reach a team of four workgroups
+    (fs_kernel.hpp, TEAM), of which a shorter reach leaves one, two or three with nothing but identity rows - they still post,
+    wait and decide with the others.  Pivoted C oracle, 1e-8, identical Newton counts; the sentinel padding is never read."""
+    from flowsim_amd import _abi as A
+    from oracle import c_oracle
+    from synth import rect_problem
+    lengths = [4097, 9999, 16384, 6145, 12289]
+    probs = [rect_problem(n, seed=1500 + s, n_steps=3) for s, n in enumerate(lengths)]
+    with _uniform_batch(probs, "rect_uniform", max(lengths), lengths) as b:
+        b.step(3)
+        e = A.kernel_table()[b.kernel_index()]
+        assert e["team"] == 1 and e["long_reach"] == 0
+        assert np.all(b.status() == 0), b.status()
+        h, Q = b.history_arrays(0, 4)
+        its = b.iterations(0, 4)
+        hyd = b.hydrographs(0, 4)
+    for r, (n, q) in enumerate(zip(lengths, probs)):
+        ref = c_oracle.run(q)
+        assert rel(h[:, r, :n], ref["depth"], 1e-3) <= TOL and rel(Q[:, r, :n], ref["flow"], 1.0) <= TOL, n
+        assert np.array_equal(its[:, r], ref["iters"]), n
+        assert np.array_equal(hyd[:, 2, r], h[:, r, n - 1]) and np.array_equal(hyd[:, 3, r], Q[:, r, n - 1])
+
+
+def test_team_kernel_is_deterministic_and_chunk_invariant_at_size():
+    """1 024 reaches x 16 384 nodes (4 096 workgroups meeting once per Newton iteration through device memory, sixteen rounds of the
+    chip): two runs give the same bits, stepping level by level gives the same bits as one launch, every reach converges with the
+    counts of the first run, and three of the reaches agree with the pivoted C oracle."""
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+    from flowsim_amd.synthetic import c3_reach_parameters, inflow_table, normal_depth_rect
+    from oracle import c_oracle
+    B, N, K = 1024, 16384, 4
+    b_, n_, S0, Qb = c3_reach_parameters(0, B); hn = normal_depth_rect(b_, n_, S0, Qb); L = (N - 1) * 250.0
+
+    def run(chunks):
+        with PreissmannBatch(B, N, K + 1, section_mode="rect_uniform", monitor=False) as bt:
+            bt.set_scheme(0.6, 600.0, 250.0, 1e-6, 100); bt.set_geometry_uniform(b_, n_, S0 * L, np.zeros(B))
+            bt.set_boundary(A.UPSTREAM, BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, inflow_table(Qb, K + 1, 600.0)))
+            bt.set_boundary(A.DOWNSTREAM, BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=S0, bed_level=np.zeros(B))))
+            bt.set_state_uniform(hn, Qb)
+            for c in chunks:
+                bt.step(c)
+            assert A.kernel_table()[bt.kernel_index()]["team"] == 1
+            assert np.all(bt.status() == 0)
+            return bt.hydrographs(0, K + 1), bt.iterations(0, K + 1), bt.state()
+    one, again, chunked = run([K]), run([K]), run([1] * K)
+    for other in (again, chunked):
+        assert np.array_equal(one[0], other[0]) and np.array_equal(one[1], other[1])
+        assert np.array_equal(one[2][0], other[2][0]) and np.array_equal(one[2][1], other[2][1])
+    tgt = inflow_table(Qb, K + 1, 600.0)
+    for r in (0, 511, 1023):
+        geo = {k: np.zeros(N) for k in O.GEO_KEYS}
+        geo["b_main"][:] = b_[r]; geo["n_main"][:] = n_[r]; geo["n_left"][:] = n_[r]; geo["n_right"][:] = n_[r]
+        geo["z_bed"] = S0[r] * L * (1 - np.arange(N) / (N - 1))
+        p = O.Problem(geo=geo, h0=np.full(N, hn[r]), Q0=np.full(N, Qb[r]), us=O.BC("flow_hydrograph", bed_level=S0[r] * L, target=tgt[:, r].copy()),
+                      ds=O.BC("normal_depth", bed_level=0.0, bed_slope=float(S0[r])), theta=0.6, dt=600.0, dx=250.0, nt=K + 1, tol=1e-6)
+        ref = c_oracle.run(p)
+        assert np.array_equal(one[1][:, r], ref["iters"])
+        assert rel(one[0][:, 2, r], ref["depth"][:, -1], 1e-3) <= TOL and rel(one[0][:, 3, r], ref["flow"][:, -1], 1.0) <= TOL
+        assert rel(one[2][0][r], ref["depth"][-1], 1e-3) <= TOL and rel(one[2][1][r], ref["flow"][-1], 1.0) <= TOL

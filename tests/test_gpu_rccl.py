@@ -40,7 +40,10 @@ CHILD = textwrap.dedent("""
     view = torch.as_tensor(v, device="cuda:0")
     rows = view[1:1 + K].contiguous()
     out = torch.empty((1,) + tuple(rows.shape), dtype=rows.dtype, device="cuda:0")
-    dist.all_gather_into_tensor(out.view(K, 4, B), rows)                 # the collective of bench.py
+    dist.all_gather_into_tensor(out.view(K, 4, B), rows)                 # the all-ranks form of gather_hydrographs
+    out2 = torch.empty_like(out)
+    dist.gather(rows, [out2[0]], dst=0)                                  # the collective of bench.py: a gather to rank 0
+    assert torch.equal(out2, out)
     t = torch.tensor([float(K)], dtype=torch.float64, device="cuda:0")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.barrier()

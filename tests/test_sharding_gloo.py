@@ -50,13 +50,17 @@ def _worker(rank, world, port, q, strong=False):
         first, count = split_reaches(TOTAL_STRONG, rank, world)
         local = torch.from_numpy(hydrographs_of_block(first, count))
         allh = gather_hydrographs_split(local, TOTAL_STRONG, world)
+        root0 = gather_hydrographs_split(local, TOTAL_STRONG, world, 0)          # bench.py's form: to rank 0 alone
     else:
         first, count = reach_block(rank, world, PER_RANK)
         local = torch.from_numpy(hydrographs_of_block(first, count))
         allh = gather_hydrographs(local, world)
+        root0 = gather_hydrographs(local, world, 0)
     dist.barrier()
+    assert (root0 is None) == (rank != 0)
     if rank == 0:
-        q.put(allh.numpy())
+        assert torch.equal(root0, allh)
+        q.put(root0.numpy())
     dist.destroy_process_group()
 
 

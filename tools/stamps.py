@@ -17,10 +17,12 @@ out = np.zeros((B, 16, 12), dtype=np.uint64)
 lib = A.lib(); lib.fs_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 assert lib.fs_debug_stamps(bt._h, out.ctypes.data_as(C.c_void_p)) == 0
 W = bt.kernel_info()["waves_per_reach"]
-names = ["fold", "bc", "tree-up", "barrier-wait", "cross-wave", "update(+accept tail)", "down+back", "loop-top", "acc:stores", "acc:hydro", "acc:level-pass", "-"]
+if A.kernel_table()[bt.kernel_index()].get("team"):          # a team's rows: (member, wave), up to 16
+    W = min(16, W * ((N + 64 * W * bt.kernel_info()["cells_per_thread"] - 1) // (64 * W * bt.kernel_info()["cells_per_thread"])))
+names = ["fold", "bc", "tree-up", "barrier-wait", "cross-wave", "update(+accept tail)", "down+back", "loop-top", "acc:stores", "acc:hydro", "acc:level-pass", "team:post+wait"]
 per_it = out[:, :W, :].astype(np.float64) / its[:, None, None]
 print(f"kernel {bt.kernel_info()}  ms {bt.last_step_ms():.2f}  mean its/step {its.mean()/K:.2f}")
 tot = per_it.sum(axis=2).mean()
 for w in range(W):
-    print("wave", w, " ".join(f"{names[i]}={per_it[:, w, i].mean():8.0f}" for i in range(11)), f" total={per_it[:, w].sum(axis=1).mean():.0f}")
+    print("wave", w, " ".join(f"{names[i]}={per_it[:, w, i].mean():8.0f}" for i in range(12)), f" total={per_it[:, w].sum(axis=1).mean():.0f}")
 print("mean cycles/iteration/wave", tot)
