@@ -92,9 +92,9 @@ struct Entry { int dtype, sec, M, W, full, bck, diag; LaunchFn fn; KernelPtr kp;
 #define FS_TABLE_ROW_TAIL(R, DT, SEC, M, W, BCK, TAIL)                                            \
   { DT, SEC, M, W, 0, (int)(BCK), 0, &fs_launch<R, SEC, M, W, true, (int)(BCK), false, TAIL>,      \
     (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), false, TAIL>, 0, TAIL },
-#define FS_TABLE_ROW_TEAM(R, DT, SEC, M, W, BCK)                                                  \
-  { DT, SEC, M, W, 0, (int)(BCK), 1, &fs_launch_team<R, SEC, M, W, (int)(BCK)>,                    \
-    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), true, -1, true>, 0, -1, 1 },
+#define FS_TABLE_ROW_TEAM(R, DT, SEC, M, W, FULL, BCK, DIAG)                                               \
+  { DT, SEC, M, W, FULL, (int)(BCK), DIAG, &fs_launch_team<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0>,  \
+    (KernelPtr)&fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0, -1, true>, 0, -1, 1 },
 #define FS_ENTRY_X(R, DT, SEC, M, W, FULL, BCK) FS_TABLE_ROW(R, DT, SEC, M, W, FULL, BCK)
 #define FS_ENTRY(R, DT, SEC, M, W) FS_TABLE_ROW(R, DT, SEC, M, W, 0, 0)
 
@@ -132,9 +132,11 @@ const Entry kEntries[] = {FS_TABLE_ROW_NODIAG(double, FS_F64, FS_SEC_RECT_UNIFOR
                           FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 1, true) FS_ENTRY_X(float, FS_F32, FS_SEC_RECT_UNIFORM, 8, 1, 0, true)
                           FS_ENTRY(double, FS_F64, FS_SEC_TRAP_UNIFORM, 4, 1) FS_ENTRY(double, FS_F64, FS_SEC_TABLE, 4, 1)
                           FS_TABLE_ROW_LONG(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0)
-                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1)
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, 1, 1)
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, FS_BCK(FS_BC_NORMAL_DEPTH), 0)
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH), 0)
 #ifdef FS_TEAM_8X4
-                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 1)
+                          FS_TABLE_ROW_TEAM(double, FS_F64, FS_SEC_RECT_UNIFORM, 8, 4, 0, 1, 1)
 #endif
                           };
 #else
@@ -164,7 +166,7 @@ bool entry_fits(const Entry &e, int dtype, int sec, int N, int usk, int dsk, boo
   if (e.team && (N <= 4096 || N <= 64L * e.W * e.M || std::getenv("FS_NO_TEAM"))) return false;      // a team only where one workgroup does not hold the reach (FS_NO_TEAM=1: the multi-pass kernel instead)
   if (e.team) { if (const char *tm = std::getenv("FS_TEAM_M")) { if (std::atoi(tm) != e.M) return false; } }      // experiments: rows per lane of the team kernel
   if (e.longk && ((need_any && e.bck != -1) || (e.bck == 0 && beyond0))) return false;      // iteration budget / host rows: class -1 (tables, polylines)
-  if (e.full && N != cap) return false;
+  if (e.full && (e.team ? N % (64L * e.W * e.M) != 0 : N != cap)) return false;      // (a team's: a whole number of lane grids)
   if (!e.diag && need_diag) return false;
   if (need_any && e.bck != -1) return false;
   if (e.bck == 0 && beyond0) return false;

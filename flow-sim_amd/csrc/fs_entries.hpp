@@ -28,21 +28,25 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
 // members; general form (ragged, diagnostics compiled in), uniform section modes
 // (measured, profiles/round4/team_kernel.txt: 16 rows per lane - the fewest members - wins at every length; an (8, 4) shape with two
 // workgroups per CU, one computing while the other waits for its team, ties at 8 192 nodes and loses beyond: twice the members to wait for)
+// X(R, DT, SEC, M, W, FULL, BCK, DIAG); FULL: N a whole number of lane grids (every row a cell but the very last one).  The DIAG = 0 ones are the
+// benchmark shapes of bench.py --workload long (flow hydrograph in, normal depth out, no history), as the flagship has them
 #define FS_LIST_TEAM(X) \
-  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1) \
-  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0) \
-  X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 16, 4, 0)
-template <typename R, int SEC, int M, int W, int BCK>
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, 1, 1) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, 0, 1) \
+  X(double, FS_F64, FS_SEC_TRAP_UNIFORM, 16, 4, 0, 0, 1) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 0, FS_BCK(FS_BC_NORMAL_DEPTH), 0) \
+  X(double, FS_F64, FS_SEC_RECT_UNIFORM, 16, 4, 1, FS_BCK(FS_BC_NORMAL_DEPTH), 0)
+template <typename R, int SEC, int M, int W, bool RAGGED, int BCK, bool DIAG>
 void fs_launch_team(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, true, BCK, true, -1, true>), dim3(B * a.team_size), dim3(64 * W), 0, st, a);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG, -1, true>), dim3(B * a.team_size), dim3(64 * W), 0, st, a);
 }
-#define FS_INSTANTIATE_TEAM(R, DT, SEC, M, W, BCK)                                                                          \
-  template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), true, -1, true>(const fs::KernelArgs<R>); \
-  template void fs_launch_team<R, SEC, M, W, (int)(BCK)>(const void *, int, hipStream_t);
-#define FS_DECLARE_TEAM(R, DT, SEC, M, W, BCK)                                                                                     \
-  extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, true, (int)(BCK), true, -1, true>(const fs::KernelArgs<R>); \
-  extern template void fs_launch_team<R, SEC, M, W, (int)(BCK)>(const void *, int, hipStream_t);
+#define FS_INSTANTIATE_TEAM(R, DT, SEC, M, W, FULL, BCK, DIAG)                                                                          \
+  template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0, -1, true>(const fs::KernelArgs<R>); \
+  template void fs_launch_team<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0>(const void *, int, hipStream_t);
+#define FS_DECLARE_TEAM(R, DT, SEC, M, W, FULL, BCK, DIAG)                                                                                     \
+  extern template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0, -1, true>(const fs::KernelArgs<R>); \
+  extern template void fs_launch_team<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0>(const void *, int, hipStream_t);
 
 // reaches longer than one lane grid (fs_long.hpp): X(R, DT, SEC, M, W, BCK); capacity 64 M rows per wave slot x 64 slots
 #define FS_LIST_LONG(X) \

@@ -46,7 +46,7 @@ def _id(e):
 def _nodes(e):
     cap = 64 * e["cells_per_thread"] * e["waves_per_reach"]      # rows of the scalar system: N - 1 cells + the boundary row
     if e.get("team"):
-        return 2 * cap + cap // 5 + e["index"] % 9            # a team of three workgroups, the last one mostly padding
+        return 3 * cap if e["full"] else 2 * cap + cap // 5 + e["index"] % 9            # a team of three workgroups (ragged: the last one mostly padding)
     if e.get("long_reach"):
         return 2 * cap + cap // 3 + e["index"] % 7            # the multi-pass kernel (fs_long.hpp): three passes, the last one ragged
     if e["full"]:
