@@ -562,7 +562,9 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
   const int NS = a.N;
   const int N = (RAGGED && a.reach_nodes) ? a.reach_nodes[reach] : a.N, NC = N - 1;
   const int s0 = gt * M;                      // first node / row of this lane
-  const int tD = RAGGED ? NC / M : G * T - 1; // lane (of the reach's lane grid: gt) that owns node N-1 and the downstream boundary row ...
+  // lane (of the reach's lane grid: gt) that owns node N-1 and the downstream boundary row ...  (the non-team forms spelled out as they
+  // always were: the flagship's code is sensitive, at the 1 % level, to how its constants come about - profiles/round4/README.md)
+  const int tD = RAGGED ? NC / M : (kTeam ? G * T - 1 : T - 1);
   const int jD = kTail ? TAIL : (RAGGED ? NC - tD * M : M - 1);   // ... as its local node / row jD (0..M-1; tail-only form: fs_abi.hip picks the instantiation with TAIL = NC mod M)
   // tail-only form: 1.0 in the lanes up to / before the one that owns node N - 1, else 0.0 (multiplied in, never selected on)
   const R mle = (kTail && gt > tD) ? R(0) : R(1), mlt = (kTail && gt >= tD) ? R(0) : R(1);
@@ -910,7 +912,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
             // rows beyond the cells: the downstream boundary row (on p and m of node N-1), then identity rows
             if (RAGGED || c == M - 1) {
               const int k = s0 + c;
-              const bool cell = RAGGED ? (k < NC) : (gt != G * T - 1);      // (k = s0 + c counts along the whole reach)
+              const bool cell = RAGGED ? (k < NC) : (kTeam ? gt != G * T - 1 : t != T - 1);      // (k = s0 + c counts along the whole reach)
               const bool bcr = RAGGED ? (k == NC) : true;
               if (!cell) {
                 BCRow<R> Dr = Drow;

@@ -52,3 +52,21 @@ __global__ void clean(double *p) { p[threadIdx.x] += 1.0; }
     assert r.returncode == 1, r.stdout
     assert "device function emitted out of line" in r.stdout and "helper" in r.stdout
     assert "call instruction(s)" in r.stdout and "clean" not in r.stdout.split("VIOLATION")[1]
+
+
+def test_benchmark_kernels_have_the_recorded_machine_code():
+    """The flagship kernel loses or gains a per cent through source changes it never executes (tools/isa_digest.py): the machine code
+    of the shipped benchmark kernels is recorded with the round's measurements, and a build whose code moved fails here until it has
+    been measured again and the record rewritten (python3 tools/isa_digest.py --write)."""
+    import json
+    objs = [os.path.join(CSRC, "build", f) for f in ("fs_part_nodiag.o", "fs_part_team.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("no build directory next to the library")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_digest
+    want = json.load(open(isa_digest.RECORD))
+    got = {}
+    for o in objs:
+        got.update(isa_digest.digests(o))
+    moved = sorted(k for k in want if got.get(k, {}).get("md5") != want[k]["md5"])
+    assert not moved and set(got) == set(want), ("kernels whose machine code differs from profiles/round4/isa_digests.json", moved, sorted(set(got) ^ set(want)))
