@@ -788,7 +788,11 @@ __device__ __forceinline__ void merge(const Seg<R> &X, const Seg<R> &Y, Seg<R> &
   const R ru2 = fma_(-Y.u1, X.rc, Y.ru);          // Y's rows on m_{b-1} instead of p_b
   const R rd2 = fma_(-Y.d1, X.rc, Y.rd);
   const R det = fma_(X.d3, Y.u1, X.d2);           // | d2 d3 ; -u1' 1 |
+#ifdef FS_FAKE_TREE_RCP      // timing experiment only (wrong numbers): the merge without its reciprocal - what a reciprocal-free tree could gain at most
+  const R r = det;
+#else
   const R r = frcp(det);
+#endif
   const R g2 = X.d3 * r;
   const R A1 = r * X.d1, A2 = g2 * Y.u3, A3 = fma_(r, X.rd, -(g2 * ru2));
   e.A1 = A1; e.A2 = A2; e.A3 = A3; e.rc = X.rc;
