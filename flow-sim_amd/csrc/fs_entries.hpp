@@ -27,7 +27,10 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
 // reaches longer than one lane grid as a team of workgroups (fs_kernel.hpp, TEAM): X(R, DT, SEC, M, W, BCK); 64 W M rows per member, up to 64 / W
 // members; general form (ragged, diagnostics compiled in), uniform section modes
 // (measured, profiles/round4/team_kernel.txt: 16 rows per lane - the fewest members - wins at every length; an (8, 4) shape with two
-// workgroups per CU, one computing while the other waits for its team, ties at 8 192 nodes and loses beyond: twice the members to wait for)
+// workgroups per CU, one computing while the other waits for its team, ties at 8 192 nodes and loses beyond: twice the members to wait for.
+// A TABLE (8, 4) team - 2 048 rows per member, 512 registers + 992 B of scratch - gains 3 - 7 % on cases/gerd_roseires at 25 m and 10 m
+// (1.91e5 against 1.84e5, 8.2e4 against 7.7e4): a compound-section reach is bound by its section evaluations, not by the passes' traffic;
+// not kept)
 // X(R, DT, SEC, M, W, FULL, BCK, DIAG); FULL: N a whole number of lane grids (every row a cell but the very last one).  The DIAG = 0 ones are the
 // benchmark shapes of bench.py --workload long (flow hydrograph in, normal depth out, no history), as the flagship has them
 #define FS_LIST_TEAM(X) \

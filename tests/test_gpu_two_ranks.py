@@ -2,7 +2,7 @@
 --nproc-per-node 2 bench.py --gpus 2 --share-device --backend gloo ...` drive libflowsim_hip.so on cuda:0 (two processes, two
 HIP contexts, two batches) and exchange the boundary hydrographs over gloo; what is checked is everything of the multi-GPU
 path that does not depend on the fabric: rank -> reach-block mapping (weak: rank r owns [r B, (r+1) B); strong:
-split_reaches), the per-rank parameter draws, the padded all_gather of unequal blocks, the timing reductions, the JSON line.
+split_reaches), the per-rank parameter draws, the padded gather of unequal blocks to rank 0, the timing reductions, the JSON line.
 The gathered hydrographs of the two-rank run must equal those of a ONE-process run over the same global reaches bit for bit
 (reaches are independent; a reach's result may not depend on which rank or batch position it ran at).
 (The launcher starts before anything touches the GPU; the test process itself only counts as the third GPU user.)"""
@@ -27,7 +27,7 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_bench(extra, dump, ranks):
+def run_bench(extra, dump, ranks, common=None):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     bench = os.path.join(ROOT, "bench.py")
     if ranks == 1:
@@ -35,7 +35,7 @@ def run_bench(extra, dump, ranks):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
                "--master-port", str(free_port()), bench, "--gpus", str(ranks), "--share-device", "--backend", "gloo"]
-    r = subprocess.run(cmd + COMMON + extra + ["--dump-hydrographs", dump], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    r = subprocess.run(cmd + (common or COMMON) + extra + ["--dump-hydrographs", dump], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]                       # ONE JSON line, from rank 0
@@ -62,3 +62,17 @@ def test_two_ranks_equal_one_process_bit_for_bit(layout, tmp_path):
     assert abs(line2["value"] - total * 4 / (line2["ms_per_step"] * 4e-3)) <= 1e-6 * line2["value"]
     assert line1["n_gpus"] == 1 and len(line1["config"]["ranks"]) == 1 and line1["config"]["ranks"][0]["reaches"] == total
     assert line1["config"]["mean_newton_iterations_per_step"] == pytest.approx(line2["config"]["mean_newton_iterations_per_step"], rel=1e-12)
+
+
+def test_two_processes_step_long_reaches_on_one_gpu_at_the_same_time(tmp_path):
+    """Reaches of 12 000 nodes: every reach a TEAM of three workgroups that meet once per Newton iteration through device memory
+    (fs_kernel.hpp, TEAM).  Two processes launch such kernels on the one GPU at the same time - 768 workgroups each, more than the chip
+    holds at once, so the two grids interleave on the CUs.  Membership by ticket means a team never waits for a workgroup that cannot
+    start, whatever the other process occupies: both runs complete, every reach converges, and the gathered hydrographs equal those of
+    one process stepping all 512 reaches, bit for bit."""
+    common = ["--nodes", "12000", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--workload", "long"]
+    line2, hyd2 = run_bench(["--reaches", "256"], str(tmp_path / "two.npy"), 2, common)
+    line1, hyd1 = run_bench(["--reaches", "512"], str(tmp_path / "one.npy"), 1, common)
+    assert hyd2.shape == (4, 4, 512) and np.array_equal(hyd2, hyd1)
+    assert line2["config"]["all_converged"] and line1["config"]["all_converged"]
+    assert line2["config"]["kernel"]["team"] == 1 and line1["config"]["kernel"]["team"] == 1
