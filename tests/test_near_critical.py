@@ -155,3 +155,25 @@ def test_mirror_sets_the_channel_up_as_the_reference_does(case):
     for k in ("z_bed", "b_main", "m_main", "n_main", "is_compound", "h_bf"):
         np.testing.assert_allclose(solver.channel.node_geometry[k], fx["geo_" + k], rtol=1e-13, atol=1e-15, err_msg=k)
     np.testing.assert_allclose(solver.channel.initial_conditions, fx["initial_conditions"], rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_a_batch_without_history_watches_its_conditioning_by_default():
+    """PreissmannBatch(monitor=True) is the default since round 4 (the reference's `diagnos` check is per run, preissmann.py:133-144): a
+    batch that keeps neither history nor trace still runs the kernels that carry the conditioning monitor.  The four outliers of round 2's
+    supercritical scan (profiles/round2/supercritical_scan.txt: seeds 5932, 6685, 6373, 5684 - Froude 1.08 ... 1.48, 1.5e-4 ... 8e-3 away from
+    the pivoted oracle) come back flagged from such a batch.  (monitor=False - what bench.py asks for - selects the kernels compiled without
+    diagnostics where the batch's shape has one.)"""
+    import test_gpu_random_cases as T
+    from fixture_batch import batch_from_problems
+    from flowsim_amd import _abi as A
+    for seed in (5932, 6685, 6373, 5684):
+        p, info = T.random_problem(seed)
+        mode = "rect_uniform" if (not info["trapezoid"] and info["ds"] != "blend") else "table"
+        with batch_from_problems([p], mode=mode, history=False, monitor=True) as b:       # (the helper's default follows `history`; PreissmannBatch's is True)
+            b.step(p.nt - 1)
+            assert int(b.status()[0]) == ILL, (seed, b.status())
+            assert A.kernel_table()[b.kernel_index()]["diag"] == 1
+    from flowsim_amd import PreissmannBatch
+    import inspect
+    assert inspect.signature(PreissmannBatch.__init__).parameters["monitor"].default is True
