@@ -355,6 +355,7 @@ struct fs_batch {
   size_t team_mail_elems = 0;
   unsigned long long *team_sync = nullptr;      // [1 + B] ticket counter + per-reach post counters, zeroed before every launch
   int team_size = 0;
+  uint32_t team_epoch = 0;             // team launches made on this handle (the high half of the tagged mailbox's tags)
 };
 
 namespace {
@@ -515,7 +516,7 @@ template <typename R> void fill_args(const fs_batch *b, int n_steps, fs::KernelA
   a.hist_h = (R *)b->hist_h; a.hist_Q = (R *)b->hist_Q;
   a.dbg = b->dbg;
   a.kc_scratch = (R *)b->kc_scratch; a.passes = b->passes;
-  a.team_size = b->team_size; a.team_mail = (R *)b->team_mail; a.team_sync = b->team_sync;
+  a.team_size = b->team_size; a.team_mail = (R *)b->team_mail; a.team_sync = b->team_sync; a.team_epoch = b->team_epoch;
   a.iter_budget = 0; a.it_done = b->it_done;
 }
 
@@ -548,12 +549,15 @@ int launch_steps(fs_batch *b, int n_steps, int iter_budget) {
   if (k->team) {       // G workgroups per reach: their mailboxes and counters (the counters start every launch at zero)
     const size_t chunk = (size_t)64 * k->W * k->M, B = b->d.n_reaches;
     b->team_size = (int)((b->d.n_nodes + chunk - 1) / chunk);
-    const size_t need = B * 2 * ((size_t)b->team_size * k->W + 1) * fs::kTeamWords;
+    // (16 bytes per word: the tagged form posts (value, tag) pairs; zeroed once - a tag is never 0, launches count from 1)
+    const size_t need = B * 2 * ((size_t)b->team_size * k->W + 1) * fs::kTeamWords * 2;
     if (b->team_mail_elems < need) {
       if (b->team_mail) { (void)hipFree(b->team_mail); b->team_mail = nullptr; b->team_mail_elems = 0; }
-      HIP_TRY(hipMalloc(&b->team_mail, need * b->esz));
+      HIP_TRY(hipMalloc(&b->team_mail, need * sizeof(double)));
+      HIP_TRY(hipMemsetAsync(b->team_mail, 0, need * sizeof(double), b->stream));
       b->team_mail_elems = need;
     }
+    ++b->team_epoch;
     if (!b->team_sync) HIP_TRY(hipMalloc((void **)&b->team_sync, (1 + B) * sizeof(unsigned long long)));
     HIP_TRY(hipMemsetAsync(b->team_sync, 0, (1 + B) * sizeof(unsigned long long), b->stream));
   }

@@ -222,6 +222,7 @@ template <typename R> struct KernelArgs {
   int32_t team_size;             // G: workgroups per reach, member g owns rows [g C, (g + 1) C), C = 64 W M
   R *team_mail;                  // [B][2][G W + 1][kTeamWords] mailboxes: one slot per (member, wave) + one for the upstream row, per iteration parity
   unsigned long long *team_sync; // [1 + B]: [0] the ticket counter of the launch, [1 + reach] posts made for that reach so far (zeroed before every launch)
+  uint32_t team_epoch;           // tagged mailbox (FS_TEAM_TAGGED): the number of this launch among the handle's team launches (>= 1): the high half of every tag
 };
 constexpr int kTeamSlots = 64;   // (member, wave) segments of a team: the top tree is one wave wide
 constexpr int kTeamWords = 12;   // per slot: the segment (8), the wave's residual sum (1), two ints (monitor word, boundary flag), pad
@@ -236,6 +237,22 @@ template <typename R, int SEC> struct Geometry;
 // bumps the reach's counter after it; a reader polls the counter, passes a barrier, and only then issues its loads.
 template <typename T> __device__ __forceinline__ void team_put(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void team_posted() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Tagged form (FS_TEAM_TAGGED): every mailbox word travels as ONE 16-byte device-coherent store of (value, tag), tag = (launch, exchange);
+// a reader polls the words themselves until every tag is the one it waits for.  No counter, no acknowledged stores, no barrier between
+// posting and counting: the exchange is one store flight and the reader's polls.  (A lane's aligned 16-byte access is one request.)
+#ifndef FS_TEAM_TAGGED
+#define FS_TEAM_TAGGED 1
+#endif
+typedef unsigned int fs_u4 __attribute__((ext_vector_type(4)));
+constexpr int kTeamAuxSc1 = 16;      // cache-policy operand of the raw buffer intrinsics on gfx94x / gfx950: sc1 (device-coherent)
+__device__ __forceinline__ void team_put2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned long long bits, unsigned long long tag) {
+  fs_u4 v;
+  v.x = (unsigned)bits; v.y = (unsigned)(bits >> 32); v.z = (unsigned)tag; v.w = (unsigned)(tag >> 32);
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, kTeamAuxSc1);
+}
+__device__ __forceinline__ fs_u4 team_get2(__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kTeamAuxSc1); }
+__device__ __forceinline__ unsigned long long team_tag(fs_u4 v) { return ((unsigned long long)v.w << 32) | v.z; }
+__device__ __forceinline__ unsigned long long team_bits(fs_u4 v) { return ((unsigned long long)v.y << 32) | v.x; }
 
 // the descriptor with its kind pinned to what the instantiation was compiled for (BCK >= 2)
 template <int BCK, int SIDE, typename R>
@@ -550,6 +567,13 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
   const int G = kTeam ? a.team_size : 1;
   const int reach = kTeam ? job / G : job, member = kTeam ? job - reach * G : 0;
   const int gt = member * T + t;                 // the lane's place in the reach's lane grid (t itself unless the reach is a team's)
+  constexpr bool kTagged = kTeam && FS_TEAM_TAGGED && sizeof(R) == 8;
+  // the reach's mailbox of one iteration parity as a raw buffer (tagged form: (G W + 1) slots of kTeamWords (value, tag) pairs)
+  auto mbox = [&](int par) __attribute__((always_inline)) {
+    const size_t bytes = (size_t)(G * W + 1) * kTeamWords * 16;
+    char *base = reinterpret_cast<char *>(a.team_mail) + ((size_t)reach * 2 + par) * bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x27000);
+  };
   // One Newton iteration per launch for batches with host-evaluated boundary rows (FS_BC_HOST_ROW, fs_batch_iterate): the
   // kernels of boundary class -1 carry an iteration budget and the count of the open level across launches.
   constexpr bool kBudget = (BCK == -1);
@@ -867,8 +891,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
         if (gt == 0) {                          // upstream row on (p_0, m_0): aU p_0 + bU m_0 = -res
           const R x = Urow.dh * i2tL, y = Urow.dq * i2c;
           if constexpr (kTeam) {                // (a team's: into the mailbox, next to the segments)
+            if constexpr (kTagged) {
+              const unsigned o = (unsigned)(G * W) * kTeamWords * 16u;
+              const unsigned long long tg = ((unsigned long long)a.team_epoch << 32) | (unsigned)(exchanges + 1);
+              const __amdgpu_buffer_rsrc_t mb = mbox(parity);
+              team_put2(mb, o, __double_as_longlong((double)(x + y)), tg); team_put2(mb, o + 16, __double_as_longlong((double)(x - y)), tg);
+              team_put2(mb, o + 32, __double_as_longlong((double)(-Urow.res)), tg);
+            } else {
             R *q = a.team_mail + (((size_t)reach * 2 + parity) * (G * W + 1) + G * W) * kTeamWords;
             team_put(q + 0, x + y); team_put(q + 1, x - y); team_put(q + 2, -Urow.res);
+            }
           } else {
           sm.xbc[parity][0] = x + y; sm.xbc[parity][1] = x - y; sm.xbc[parity][2] = -Urow.res;
           }
@@ -991,6 +1023,16 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       nrm2 = wave_sum(nrm2);
       if constexpr (kTeam) {
         const int wflag = __builtin_amdgcn_ballot_w64(myflag != 0) != 0 ? (int)FS_STORAGE_RANGE : 0;      // raised by a lane of this wave
+        if constexpr (kTagged) {
+          if (lane == 63) {
+            const unsigned o = (unsigned)(member * W + wave) * kTeamWords * 16u;
+            const unsigned long long tg = ((unsigned long long)a.team_epoch << 32) | (unsigned)(exchanges + 1);
+            const __amdgpu_buffer_rsrc_t mb = mbox(parity);
+            auto put = [&](int i, R v) __attribute__((always_inline)) { team_put2(mb, o + 16u * i, __double_as_longlong((double)v), tg); };
+            put(0, seg.u1); put(1, seg.u3); put(2, seg.ru); put(3, seg.d1); put(4, seg.d2); put(5, seg.d3); put(6, seg.rd); put(7, seg.rc); put(8, nrm2);
+            team_put2(mb, o + 16u * 9, ((unsigned long long)(unsigned)wflag << 32) | (unsigned)gi, tg);
+          }
+        } else {
         if (lane == 63) {                    // the wave's slot of the team's mailbox (device memory; published by the release below)
           R *p = a.team_mail + (((size_t)reach * 2 + parity) * (G * W + 1) + (member * W + wave)) * kTeamWords;
           team_put(p + 0, seg.u1); team_put(p + 1, seg.u3); team_put(p + 2, seg.ru); team_put(p + 3, seg.d1); team_put(p + 4, seg.d2);
@@ -999,6 +1041,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
           team_put(pi, gi); team_put(pi + 1, wflag);
         }
         team_posted();
+        }
       } else
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
@@ -1022,6 +1065,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       if constexpr (kPre >= 1) pre5 = load_rec_early(std::integral_constant<int, 5>{});
       if constexpr (kPre >= 2) pre4 = load_rec_early(std::integral_constant<int, 4>{});
       if constexpr (kPre >= 3) pre3 = load_rec_early(std::integral_constant<int, 3>{});
+      // (the tagged team form could do without this barrier - wave 0 polls the mailbox for every wave's post, its own workgroup's included - and is
+      // 6 % SLOWER without it: a wave 0 that starts polling while its neighbours still fold takes their issue slots and their memory path)
       __syncthreads();
       FS_T(3);
       // rc of the lane's rows for the back-substitution (step 5) does not depend on the solve: computed here, its instructions
@@ -1050,7 +1095,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
         // (every poster has seen its stores acknowledged before the __syncthreads above, thread 0 counts the workgroup in after it; the
         // counter of a reach only grows: the e-th exchange of the launch is complete when it reaches e G)
         ++exchanges;
-        if (t == 0) {
+        if (!kTagged && t == 0) {
           unsigned long long *cnt = a.team_sync + 1 + reach;
           __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned long long want = (unsigned long long)exchanges * (unsigned long long)G;
@@ -1064,23 +1109,53 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
           sm.xstall = stall;
         }
         FS_T(11);
-        __syncthreads();
+        if constexpr (!kTagged) __syncthreads();
         if (wave == 0) {
           // the top tree over the S = G W posted segments, one per lane, identity segments beyond (the multi-pass kernel's, fs_long.hpp)
           const int S = G * W;
+          Seg<R> xs;
+          R nr, aU, bU, rU;
+          int gx, fl;
+          if constexpr (kTagged) {
+            // lane s polls the ten words of slot s, every lane the three of the upstream row, until all carry this exchange's tag
+            const unsigned long long want = ((unsigned long long)a.team_epoch << 32) | (unsigned)exchanges;
+            const __amdgpu_buffer_rsrc_t mb = mbox(parity);
+            const unsigned o = (unsigned)(lane < S ? lane : 0) * kTeamWords * 16u, ou = (unsigned)S * kTeamWords * 16u;
+            const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+            fs_u4 w[13];
+            int stall = 0;
+            for (;;) {
+#pragma unroll
+              for (int i = 0; i < 10; ++i) w[i] = team_get2(mb, o + 16u * i);
+#pragma unroll
+              for (int i = 0; i < 3; ++i) w[10 + i] = team_get2(mb, ou + 16u * i);
+              bool ok = true;
+#pragma unroll
+              for (int i = 0; i < 13; ++i) ok = ok && team_tag(w[i]) == want;
+              if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+              __builtin_amdgcn_s_sleep(1);
+              if (__builtin_amdgcn_s_memtime() - t_in > 4000000000ull) { stall = 1; break; }     // ~2 s: give the reach up, do not spin on
+            }
+            if (lane == 0) sm.xstall = stall;
+            auto val = [&](int i) { return (R)__longlong_as_double((long long)team_bits(w[i])); };
+            xs.u1 = val(0); xs.u3 = val(1); xs.ru = val(2); xs.d1 = val(3); xs.d2 = val(4); xs.d3 = val(5); xs.rd = val(6); xs.rc = val(7);
+            nr = val(8);
+            gx = (int)(unsigned)team_bits(w[9]); fl = (int)(unsigned)(team_bits(w[9]) >> 32);
+            aU = val(10); bU = val(11); rU = val(12);
+          } else {
           const R *mail = a.team_mail + ((size_t)reach * 2 + parity) * (S + 1) * kTeamWords;
           const R *q = mail + (size_t)(lane < S ? lane : 0) * kTeamWords;
           auto ld = [&](int i) { return __hip_atomic_load(q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-          Seg<R> xs;
           xs.u1 = ld(0); xs.u3 = ld(1); xs.ru = ld(2); xs.d1 = ld(3); xs.d2 = ld(4); xs.d3 = ld(5); xs.rd = ld(6); xs.rc = ld(7);
-          R nr = ld(8);
+          nr = ld(8);
           const int32_t *qi = reinterpret_cast<const int32_t *>(q + 9);
-          int gx = __hip_atomic_load(qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          int fl = __hip_atomic_load(qi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gx = __hip_atomic_load(qi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          fl = __hip_atomic_load(qi + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          aU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          rU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (lane >= S) { xs.u1 = R(0); xs.u3 = R(0); xs.ru = R(0); xs.d1 = R(0); xs.d2 = R(1); xs.d3 = R(0); xs.rd = R(0); xs.rc = R(0); nr = R(0); gx = 0; fl = 0; }
-          const R aU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const R bU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const R rU = __hip_atomic_load(mail + (size_t)S * kTeamWords + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const R u1o = xs.u1, u3o = xs.u3, ruo = xs.ru;
           auto xup = [&](auto lc) __attribute__((always_inline)) {
             constexpr int l = decltype(lc)::value;
