@@ -1030,15 +1030,20 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
     return 0;
   }
   if (kind == FS_BC_STORAGE_CURVE) {
-    if (per_reach) return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE parameters are shared by the batch (per_reach = 0)");
+    // shared by the batch (params[n_params]) or - round 4 - one reservoir per reach (per_reach = 1: params[n_params][B], every reach its own
+    // scalars, area curve and outflow rating curve; the curves of a batch have the same number of points)
     if (!params || n_params < FS_SC_NFIXED) return fail("Insufficient arguments for boundary condition.");
-    const int nc = (int)params[FS_SC_N_CURVE];
-    if (nc < 0 || nc == 1 || n_params != FS_SC_NFIXED + 2 * nc)
-      return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE needs FS_SC_NFIXED + 2*n_curve parameters (n_curve 0 or >= 2)");
-    for (int j = 0; j + 1 < nc; ++j)
-      if (!(params[FS_SC_NFIXED + j + 1] > params[FS_SC_NFIXED + j]))
-        return fail("fs_batch_set_bc: area-curve stages must be increasing");
-    if (nc == 0 && !(params[FS_SC_SURFACE_AREA] > 0)) return fail("Insufficient arguments for boundary condition.");
+    const size_t Bn = per_reach ? (size_t)b->d.n_reaches : 1;
+    auto at = [&](int i, size_t r) { return per_reach ? params[(size_t)i * Bn + r] : params[i]; };
+    for (size_t r = 0; r < Bn; ++r) {
+      const int nc = (int)at(FS_SC_N_CURVE, r);
+      if (nc < 0 || nc == 1 || n_params != FS_SC_NFIXED + 2 * nc)
+        return fail("fs_batch_set_bc: FS_BC_STORAGE_CURVE needs FS_SC_NFIXED + 2*n_curve parameters (n_curve 0 or >= 2; per reach: the same n_curve for all)");
+      for (int j = 0; j + 1 < nc; ++j)
+        if (!(at(FS_SC_NFIXED + j + 1, r) > at(FS_SC_NFIXED + j, r)))
+          return fail("fs_batch_set_bc: area-curve stages must be increasing");
+      if (nc == 0 && !(at(FS_SC_SURFACE_AREA, r) > 0)) return fail("Insufficient arguments for boundary condition.");
+    }
   } else if (n_params != need[kind]) return fail("Insufficient arguments for boundary condition.");      // boundary.py:83
   if (n_params > 0 && !params) return fail("Insufficient arguments for boundary condition.");
   if ((kind == FS_BC_FLOW_HYDROGRAPH || kind == FS_BC_STAGE_HYDROGRAPH) && !target)

@@ -166,9 +166,23 @@ class PreissmannBatch:
             return
         if spec.kind == A.BC_STORAGE_CURVE:
             # general LumpedStorage: the FS_SC_* scalars (missing ones default to 0, alpha to 1) + the area curve
-            curve = np.asarray(spec.params.get("curve", np.empty((0, 2))), dtype=np.float64).reshape(-1, 2)
+            curve = np.asarray(spec.params.get("curve", np.empty((0, 2))), dtype=np.float64)
             sc = {"alpha": 1.0}
             sc.update({k: v for k, v in spec.params.items() if k != "curve"})
+            per_reach = curve.ndim == 3 or any(np.ndim(v) > 0 for v in sc.values() if v is not None)
+            if per_reach:       # one reservoir per reach: scalars [B] (or shared), curve [B, n_curve, 2] (or shared [n_curve, 2])
+                curve = np.broadcast_to(curve.reshape((-1,) + curve.shape[-2:]) if curve.size else np.empty((1, 0, 2)), (self.B,) + curve.shape[-2:])
+                nc = curve.shape[1]
+                sc["n_curve"] = float(nc)
+                p = np.empty((len(A.SC_NAMES) + 2 * nc, self.B), dtype=np.float64)
+                for i, k in enumerate(A.SC_NAMES):
+                    v = sc.get(k)
+                    p[i] = 0.0 if v is None else v
+                p[len(A.SC_NAMES):len(A.SC_NAMES) + nc] = curve[:, :, 0].T
+                p[len(A.SC_NAMES) + nc:] = curve[:, :, 1].T
+                A.check(self._lib.fs_batch_set_bc(self._h, side, spec.kind, _dptr(p), p.shape[0], 1, None), "set_boundary")
+                return
+            curve = curve.reshape(-1, 2)
             sc["n_curve"] = float(len(curve))
             p = np.concatenate([[float(sc.get(k) or 0.0) for k in A.SC_NAMES], curve[:, 0], curve[:, 1]])
             A.check(self._lib.fs_batch_set_bc(self._h, side, spec.kind, _dptr(p), len(p), 0, None), "set_boundary")

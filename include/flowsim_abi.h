@@ -88,7 +88,9 @@ enum {
                                  (lumped_storage.py:24-35) is found on the device with the algorithm of
                                  scipy.optimize.brentq and its default tolerances.  Section modes
                                  FS_SEC_TABLE and FS_SEC_IRREGULAR only (fs_batch_step refuses it in the
-                                 uniform-geometry modes: describe such a channel as a table). */
+                                 uniform-geometry modes: describe such a channel as a table).  Shared by the
+                                 batch (per_reach = 0) or one reservoir per reach (per_reach = 1:
+                                 params[FS_SC_NFIXED + 2*n_curve][B], the same n_curve for every reach). */
   FS_BC_HOST_ROW = 9          /* a boundary whose plugin has no device form: any object with discharge(stage, time) /
                                  dQ_dz(stage, time) (rating_curve.py:32-63,:132-147; e.g. RoseiresRatingCurve(smooth=False),
                                  cases/gerd_roseires/roseires_rating_curve.py:65-140, whose gates move with time) or a
@@ -195,7 +197,8 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
  *   fs_batch_set_bc_per_reach                  kinds[B] (FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE), params[FS_BC_MAX_PARAMS][B] (row i
  *                                              = parameter i of the reach's own kind, unused rows ignored), target[max_levels][B].
  * Time level k of reach r is t = k * dt[r]: targets are sampled per reach.  These batches run on the general kernels (run-time
- * boundary switch, ragged node counts); the kinds FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW stay batch-wide (fs_batch_set_bc). */
+ * boundary switch, ragged node counts); the kinds FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW stay batch-wide as KINDS (fs_batch_set_bc) - a batch of
+ * general reservoirs may still give every reach its own (per_reach = 1 there: scalars, area curve, outflow curve). */
 int fs_batch_set_geometry_table_per_reach(fs_batch *b, const double *tables, const double *n_main_override);
 int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables, const int32_t *n_pts, int32_t max_pts,
                                               const double *x, const double *z, const double *limits,

@@ -53,8 +53,15 @@ def merge_specs(specs, B):
     kind = specs[0].kind
     assert all(s.kind == kind for s in specs)
     if kind == A.BC_STORAGE_CURVE:
-        assert B == 1, "general storage parameters are shared by the batch"
-        return specs[0]
+        if B == 1:
+            return specs[0]
+        # one reservoir per reach (round 4): scalars [B], area curves [B, n_curve, 2] with the same number of points
+        keys = sorted({k for s in specs for k in s.params if k != "curve"})
+        params = {k: np.array([float(s.params.get(k) or (1.0 if k == "alpha" else 0.0)) for s in specs]) for k in keys}
+        curves = [np.asarray(s.params.get("curve", np.empty((0, 2))), dtype=np.float64).reshape(-1, 2) for s in specs]
+        assert len({len(c) for c in curves}) == 1, "the area curves of one batch need the same number of points"
+        params["curve"] = np.stack(curves)
+        return BoundarySpec(kind, params)
     params = {k: np.array([s.params[k] for s in specs], dtype=np.float64) for k in specs[0].params}
     tgt = None
     if specs[0].target is not None:
