@@ -5,6 +5,7 @@
 // fs_abi.hip builds its dispatch table from them; the fs_part_*.hip translation units instantiate them (compiled in
 // parallel by the Makefile: one translation unit with all ~130 kernels takes 2.5 minutes).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include "fs_kernel.hpp"
 
@@ -42,7 +43,10 @@ void fs_launch_long(const void *args, int B, hipStream_t st) {
 template <typename R, int SEC, int M, int W, bool RAGGED, int BCK, bool DIAG>
 void fs_launch_team(const void *args, int B, hipStream_t st) {
   const fs::KernelArgs<R> &a = *static_cast<const fs::KernelArgs<R> *>(args);
-  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG, -1, true>), dim3(B * a.team_size), dim3(64 * W), 0, st, a);
+  // FS_TEAM_TEST_DROP=1 (tests only): one workgroup too few, so that the last reach's team waits for a member that never comes - the bounded
+  // wait of the exchange must then end that reach with FS_TEAM_STALL and leave the others alone (tests/test_gpu_ragged_batches.py)
+  const int grid = B * a.team_size - (std::getenv("FS_TEAM_TEST_DROP") ? 1 : 0);
+  hipLaunchKernelGGL((fs::preissmann_step_kernel<R, SEC, M, W, RAGGED, BCK, DIAG, -1, true>), dim3(grid), dim3(64 * W), 0, st, a);
 }
 #define FS_INSTANTIATE_TEAM(R, DT, SEC, M, W, FULL, BCK, DIAG)                                                                          \
   template __global__ void fs::preissmann_step_kernel<R, SEC, M, W, !(FULL), (int)(BCK), (DIAG) != 0, -1, true>(const fs::KernelArgs<R>); \

@@ -225,3 +225,30 @@ def test_one_general_reservoir_per_reach():
         assert np.array_equal(its[:, r], fx["iters"]), names[r]
         if "storage_stage" in fx.files:
             assert rel(stages[1:, r], fx["storage_stage"][:, 1], 1e-3) <= TOL, names[r]
+
+
+def test_a_team_that_misses_a_member_gives_the_reach_up_instead_of_spinning_on(monkeypatch):
+    """The exit condition of the team kernel's wait.  FS_TEAM_TEST_DROP=1 launches one workgroup too few: the last reach's team (two members
+    at 8 192 nodes) waits for a member that never starts.  After about two seconds of polling the waiting member ends its reach with
+    FS_TEAM_STALL; the other reaches complete as if nothing had happened, the launch returns, and the next launch on the handle works."""
+    import time
+    from flowsim_amd import _abi as A
+    from synth import rect_problem
+    probs = [rect_problem(8192, seed=1700 + s, n_steps=2) for s in range(4)]
+    with _uniform_batch(probs, "rect_uniform", 8192) as good:
+        good.step(2)
+        want = good.hydrographs(0, 3)
+        assert np.all(good.status() == 0) and A.kernel_table()[good.kernel_index()]["team"] == 1
+    with _uniform_batch(probs, "rect_uniform", 8192) as b:
+        monkeypatch.setenv("FS_TEAM_TEST_DROP", "1")
+        t0 = time.time()
+        b.step(2)
+        waited = time.time() - t0
+        monkeypatch.delenv("FS_TEAM_TEST_DROP")
+        st = b.status()
+        assert list(st) == [0, 0, 0, A.TEAM_STALL], st
+        assert 0.2 < waited < 60.0, waited                        # a bounded wait, not a hang
+        assert np.array_equal(b.hydrographs(0, 3)[:, :, :3], want[:, :, :3])
+    with _uniform_batch(probs, "rect_uniform", 8192) as c:       # nothing of it sticks to the device
+        c.step(2)
+        assert np.all(c.status() == 0) and np.array_equal(c.hydrographs(0, 3), want)
