@@ -506,6 +506,9 @@ template <typename R> struct LocalElim { Parked<R> R1, R2, R3, qc; };
 #endif
 template <typename R, int SEC, int M, int W, int BCK, bool TEAM = false> constexpr int min_waves() {
   if (TEAM && M <= 8 && sizeof(R) == 8) return FS_TEAM_WPE;
+#ifdef FS_WPE_TRAP42      // experiment: the (4, 2) trapezoid kernel (272 registers) capped at 256, two waves per SIMD
+  if (W == 2 && M == 4 && SEC == FS_SEC_TRAP_UNIFORM && sizeof(R) == 8) return FS_WPE_TRAP42;
+#endif
   if (W > 1) return 1;          // multi-wave table kernels with 2 cells per lane at two waves per SIMD: no better than the 4- and 8-cell ones
   if (sizeof(R) == 4) return (M <= 8 && (SEC == FS_SEC_RECT_UNIFORM || SEC == FS_SEC_TRAP_UNIFORM)) ? FS_WPE_W1_F32_UNIFORM : FS_WPE_W1_F32;
   if (SEC == FS_SEC_RECT_UNIFORM && BCK >= 1 && M <= 8) return FS_WPE_RECT8;
