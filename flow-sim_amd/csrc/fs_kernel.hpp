@@ -243,6 +243,9 @@ __device__ __forceinline__ void team_posted() { asm volatile("s_waitcnt vmcnt(0)
 #ifndef FS_TEAM_TAGGED
 #define FS_TEAM_TAGGED 1
 #endif
+#ifndef FS_TEAM_SLEEP
+#define FS_TEAM_SLEEP 1      // s_sleep between two polls of the mailbox (units of 64 cycles)
+#endif
 typedef unsigned int fs_u4 __attribute__((ext_vector_type(4)));
 constexpr int kTeamAuxSc1 = 16;      // cache-policy operand of the raw buffer intrinsics on gfx94x / gfx950: sc1 (device-coherent)
 __device__ __forceinline__ void team_put2(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned long long bits, unsigned long long tag) {
@@ -1136,7 +1139,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
 #pragma unroll
               for (int i = 0; i < 13; ++i) ok = ok && team_tag(w[i]) == want;
               if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
-              __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_s_sleep(FS_TEAM_SLEEP);
               if (__builtin_amdgcn_s_memtime() - t_in > 4000000000ull) { stall = 1; break; }     // ~2 s: give the reach up, do not spin on
             }
             if (lane == 0) sm.xstall = stall;
