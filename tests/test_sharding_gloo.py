@@ -42,15 +42,16 @@ def hydrographs_of_block(first, count):
 TOTAL_STRONG = 7      # strong scaling: 7 reaches over 2 ranks = blocks of 4 and 3
 
 
-def _worker(rank, world, port, q, strong=False):
+def _worker(rank, world, port, q, strong=False, total_strong=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     if strong:      # bench.py --total-reaches: contiguous blocks of unequal size, the shorter one travels padded
-        first, count = split_reaches(TOTAL_STRONG, rank, world)
+        total = total_strong or TOTAL_STRONG
+        first, count = split_reaches(total, rank, world)
         local = torch.from_numpy(hydrographs_of_block(first, count))
-        allh = gather_hydrographs_split(local, TOTAL_STRONG, world)
-        root0 = gather_hydrographs_split(local, TOTAL_STRONG, world, 0)          # bench.py's form: to rank 0 alone
+        allh = gather_hydrographs_split(local, total, world)
+        root0 = gather_hydrographs_split(local, total, world, 0)          # bench.py's form: to rank 0 alone
     else:
         first, count = reach_block(rank, world, PER_RANK)
         local = torch.from_numpy(hydrographs_of_block(first, count))
@@ -116,3 +117,25 @@ def test_split_reaches_covers_everything():
             f, c = split_reaches(total, r, world)
             seen += list(range(f, f + c))
         assert seen == list(range(total))
+
+
+@pytest.mark.parametrize("strong", [False, True])
+def test_eight_ranks_as_the_scaling_run_has_them(strong):
+    """The driver's scaling tier goes to --gpus 8; the build box has one GPU, so the eight-rank control flow is rehearsed here on the CPU
+    (gloo): eight processes, rank r its own block of reaches (weak: 3 each; strong: 29 reaches in blocks of 4 and 3, the shorter ones
+    padded), the gather to rank 0 and the all-ranks form, against one process stepping all the reaches - bit for bit."""
+    total = 29
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, q, strong, total)) for r in range(8)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = hydrographs_of_block(0, total if strong else 8 * PER_RANK)
+    assert got.shape == want.shape and np.array_equal(got, want)
