@@ -225,6 +225,10 @@ template <typename R> struct KernelArgs {
   uint32_t team_epoch;           // tagged mailbox (FS_TEAM_TAGGED): the number of this launch among the handle's team launches (>= 1): the high half of every tag
 };
 constexpr int kTeamSlots = 64;   // (member, wave) segments of a team: the top tree is one wave wide
+// how long a member waits for its team before it gives the reach up (FS_TEAM_STALL): s_memtime ticks, 2.0e9 per second on gfx950 (tools/micro/rates.hip:
+// 158 795 ticks in 0.079 ms of HIP-event time).  Eight seconds: a team's members start in ticket order as CUs become free, so the wait is bounded by the
+// longest kernel of a co-tenant that holds the CUs meanwhile, not by anything of this library's own
+constexpr unsigned long long kTeamPatience = 16000000000ull;
 constexpr int kTeamWords = 12;   // per slot: the segment (8), the wave's residual sum (1), two ints (monitor word, boundary flag), pad
 
 template <typename R, int SEC> struct Geometry;
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
           // (relaxed polls: an acquire per poll would invalidate the caches of the whole XCD on every turn; one acquire fence follows the wait)
           while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memtime() - t_in > 4000000000ull) { stall = 1; break; }     // ~2 s of s_memtime: give the reach up, do not spin on
+            if (__builtin_amdgcn_s_memtime() - t_in > kTeamPatience) { stall = 1; break; }     // give the reach up, do not spin on
           }
           sm.xstall = stall;
         }
@@ -1140,7 +1144,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
               for (int i = 0; i < 13; ++i) ok = ok && team_tag(w[i]) == want;
               if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
               __builtin_amdgcn_s_sleep(FS_TEAM_SLEEP);
-              if (__builtin_amdgcn_s_memtime() - t_in > 4000000000ull) { stall = 1; break; }     // ~2 s: give the reach up, do not spin on
+              if (__builtin_amdgcn_s_memtime() - t_in > kTeamPatience) { stall = 1; break; }     // give the reach up, do not spin on
             }
             if (lane == 0) sm.xstall = stall;
             auto val = [&](int i) { return (R)__longlong_as_double((long long)team_bits(w[i])); };

@@ -126,7 +126,7 @@ enum { FS_OK = 0, FS_MAX_ITER = 1, FS_NAN = 2, FS_STORAGE_RANGE = 3,
         * with FS_FLAG_HISTORY, FS_FLAG_TRACE or FS_FLAG_MONITOR, and every batch no specialised kernel exists for. */
        FS_ILL_CONDITIONED = 4,
        /* A reach longer than one lane grid is advanced by a team of workgroups that meet once per Newton iteration (uniform section
-        * modes beyond 4 096 nodes).  A member that waits for the others longer than about two seconds gives the reach up with this
+        * modes beyond 4 096 nodes).  A member that waits for the others longer than about eight seconds gives the reach up with this
         * status instead of spinning on; it has not been seen to happen (a team's members are the workgroups that started first, so
         * none of them waits for one that cannot start) and would mean a lost or wedged workgroup.  The reach's state is that of the
         * last launch that completed. */

@@ -229,7 +229,7 @@ def test_one_general_reservoir_per_reach():
 
 def test_a_team_that_misses_a_member_gives_the_reach_up_instead_of_spinning_on(monkeypatch):
     """The exit condition of the team kernel's wait.  FS_TEAM_TEST_DROP=1 launches one workgroup too few: the last reach's team (two members
-    at 8 192 nodes) waits for a member that never starts.  After about two seconds of polling the waiting member ends its reach with
+    at 8 192 nodes) waits for a member that never starts.  After about eight seconds of polling the waiting member ends its reach with
     FS_TEAM_STALL; the other reaches complete as if nothing had happened, the launch returns, and the next launch on the handle works."""
     import time
     from flowsim_amd import _abi as A
