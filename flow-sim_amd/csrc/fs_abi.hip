@@ -336,6 +336,8 @@ struct fs_batch {
   void *reach_scheme = nullptr;         // [3][B] per-reach theta, dt, dx or nullptr
   int32_t *reach_kinds = nullptr;       // [2][B] per-reach boundary kinds or nullptr
   bool kinds_per_reach[2] = {false, false};
+  bool some_host_rows[2] = {false, false};      // per-reach kinds with FS_BC_HOST_ROW among them: fs_batch_set_host_rows writes those reaches' rows only
+  void *rows_stage = nullptr;          // [3][B] what the caller handed to fs_batch_set_host_rows, before the masked merge into the parameters
   void *bc_params[2] = {nullptr, nullptr}, *bc_target[2] = {nullptr, nullptr};
   int bc_kind[2] = {0, 0}, bc_stride[2] = {0, 0};
   void *Yprev = nullptr, *stage_hist = nullptr, *trace = nullptr, *hydro = nullptr, *hist_h = nullptr, *hist_Q = nullptr;
@@ -481,6 +483,15 @@ __global__ void count_open_reaches(const int32_t *done, const int32_t *status, i
   const bool open = r < B && done[r] >= 0 && (status[r] == FS_OK || status[r] == FS_ILL_CONDITIONED);   // (a warning, not a failure)
   const unsigned long long m = __ballot(open);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int32_t)__popcll(m));
+}
+
+// fs_batch_set_host_rows on a side with per-reach kinds: the rows of the host-evaluated reaches go into parameter rows 0..2, the
+// parameters of the reaches whose kind the device evaluates stay what fs_batch_set_bc_per_reach stored
+template <typename R>
+__global__ void merge_host_rows(R *params, const R *rows, const int32_t *kinds, size_t B) {
+  const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= B || kinds[r] != FS_BC_HOST_ROW) return;
+  for (int i = 0; i < 3; ++i) params[(size_t)i * B + r] = rows[(size_t)i * B + r];
 }
 
 // level 0 of every array from one (h, Q) pair per reach
@@ -673,6 +684,7 @@ void fs_batch_destroy(fs_batch *b) {
                   b->iters, b->status, b->poly_x, b->poly_z, b->poly_lim, b->poly_n, b->it_done, b->dbg, b->reach_nodes,
                   b->reach_scheme, b->reach_kinds, b->kc_scratch, b->poly_tz, b->ends_dev, b->open_dev, b->team_mail, b->team_sync};
   for (void *p : bufs) if (p) (void)hipFree(p);
+  if (b->rows_stage) (void)hipFree(b->rows_stage);
   if (b->ends_pin) (void)hipHostFree(b->ends_pin);
   if (b->open_pin) (void)hipHostFree(b->open_pin);
   for (void *p : b->derived) if (p) (void)hipFree(p);
@@ -969,20 +981,43 @@ int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt
 }
 
 int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target) {
+  return fs_batch_set_bc_per_reach_wide(b, side, kinds, params, FS_BC_MAX_PARAMS, target);
+}
+
+int fs_batch_set_bc_per_reach_wide(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, int32_t n_params,
+                                   const double *target) {
   if (!b || !kinds || !params) return fail("fs_batch_set_bc_per_reach: null argument");
   if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc_per_reach: side must be FS_UPSTREAM or FS_DOWNSTREAM");
+  if (n_params < FS_BC_MAX_PARAMS) return fail("fs_batch_set_bc_per_reach: at least FS_BC_MAX_PARAMS parameter rows");
   FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches;
+  const bool tables = b->d.section_mode == FS_SEC_TABLE || b->d.section_mode == FS_SEC_IRREGULAR;
   bool need_target = false;
   for (size_t r = 0; r < B; ++r) {
-    if (kinds[r] < 0 || kinds[r] > FS_BC_STORAGE) return fail("fs_batch_set_bc_per_reach: kinds FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE only");
+    if (kinds[r] == FS_BC_STORAGE_CURVE) {   // a general reservoir behind THIS reach: its FS_SC_* rows, its own area curve of its own length
+      if (!tables) return fail("fs_batch_set_bc_per_reach: FS_BC_STORAGE_CURVE needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
+      if (side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
+      auto at = [&](int i) { return params[(size_t)i * B + r]; };
+      const int nc = n_params > FS_SC_N_CURVE ? (int)at(FS_SC_N_CURVE) : -1;
+      if (nc < 0 || nc == 1 || FS_SC_NFIXED + 2 * nc > n_params)
+        return fail("fs_batch_set_bc_per_reach: an FS_BC_STORAGE_CURVE reach needs FS_SC_NFIXED + 2*n_curve parameter rows (n_curve 0 or >= 2)");
+      for (int j = 0; j + 1 < nc; ++j)
+        if (!(at(FS_SC_NFIXED + j + 1) > at(FS_SC_NFIXED + j))) return fail("fs_batch_set_bc: area-curve stages must be increasing");
+      if (nc == 0 && !(at(FS_SC_SURFACE_AREA) > 0)) return fail("Insufficient arguments for boundary condition.");
+      continue;
+    }
+    if (kinds[r] == FS_BC_HOST_ROW) {      // a plugin without a device form on THIS reach (round 4: until then a batch-wide kind only)
+      if (!tables) return fail("fs_batch_set_bc_per_reach: FS_BC_HOST_ROW needs section mode FS_SEC_TABLE or FS_SEC_IRREGULAR");
+      continue;
+    }
+    if (kinds[r] < 0 || kinds[r] > FS_BC_STORAGE) return fail("Invalid boundary condition.");        // boundary.py:33
     if (kinds[r] == FS_BC_STORAGE && side != FS_DOWNSTREAM) return fail("fs_batch_set_bc: the storage boundary is downstream only");
     need_target = need_target || kinds[r] == FS_BC_FLOW_HYDROGRAPH || kinds[r] == FS_BC_STAGE_HYDROGRAPH;
   }
   if (need_target && !target) return fail("Insufficient arguments for boundary condition.");                     // boundary.py:87
   if (b->bc_params[side]) { (void)hipFree(b->bc_params[side]); b->bc_params[side] = nullptr; }
   if (b->bc_target[side]) { (void)hipFree(b->bc_target[side]); b->bc_target[side] = nullptr; }
-  if (upload(b, &b->bc_params[side], params, (size_t)FS_BC_MAX_PARAMS * B)) return -1;
+  if (upload(b, &b->bc_params[side], params, (size_t)n_params * B)) return -1;
   if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
   if (!b->reach_kinds) {
     HIP_TRY(hipMalloc((void **)&b->reach_kinds, 2 * B * 4));
@@ -996,8 +1031,15 @@ int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, c
     HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)other * B, same.data(), B * 4, hipMemcpyHostToDevice));
   }
   b->bc_kind[side] = kinds[0]; b->bc_stride[side] = 1; b->kinds_per_reach[side] = true;
-  b->any_storage[side] = false;
-  for (size_t r = 0; r < B; ++r) b->any_storage[side] = b->any_storage[side] || fs::bc_is_storage(kinds[r]);
+  b->any_storage[side] = false; b->some_host_rows[side] = false;
+  for (size_t r = 0; r < B; ++r) {
+    b->any_storage[side] = b->any_storage[side] || fs::bc_is_storage(kinds[r]);
+    b->some_host_rows[side] = b->some_host_rows[side] || kinds[r] == FS_BC_HOST_ROW;
+  }
+  // one host-evaluated reach makes the batch one that advances with fs_batch_iterate on the kernels of boundary class -1, one general
+  // reservoir makes it one for those kernels too: the side's representative kind (what the dispatch and fs_batch_step look at) says so
+  for (size_t r = 0; r < B; ++r) if (kinds[r] == FS_BC_STORAGE_CURVE) b->bc_kind[side] = FS_BC_STORAGE_CURVE;
+  if (b->some_host_rows[side]) b->bc_kind[side] = FS_BC_HOST_ROW;
   b->have_bc[side] = true;
   return 0;
 }
@@ -1022,7 +1064,7 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
       HIP_TRY(hipMemsetAsync(b->bc_params[side], 0, 3 * B * b->esz, b->stream));
     }
     b->bc_kind[side] = kind; b->bc_stride[side] = 1; b->have_bc[side] = true;
-    b->kinds_per_reach[side] = false; b->any_storage[side] = false;
+    b->kinds_per_reach[side] = false; b->any_storage[side] = false; b->some_host_rows[side] = false;
     if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
       std::vector<int32_t> same(B, kind);
       HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
@@ -1056,7 +1098,7 @@ int fs_batch_set_bc(fs_batch *b, int32_t side, int32_t kind, const double *param
   if (target && upload(b, &b->bc_target[side], target, (size_t)b->d.max_levels * B)) return -1;
   b->bc_kind[side] = kind; b->bc_stride[side] = per_reach ? 1 : 0;
   b->have_bc[side] = true;
-  b->kinds_per_reach[side] = false; b->any_storage[side] = fs::bc_is_storage(kind);
+  b->kinds_per_reach[side] = false; b->any_storage[side] = fs::bc_is_storage(kind); b->some_host_rows[side] = false;
   if (b->reach_kinds) {          // the other side has per-reach kinds: this side's one kind goes into every slot
     std::vector<int32_t> same(B, kind);
     HIP_TRY(hipMemcpy(b->reach_kinds + (size_t)side * B, same.data(), B * 4, hipMemcpyHostToDevice));
@@ -1175,7 +1217,19 @@ int fs_batch_set_host_rows(fs_batch *b, int32_t side, const double *rows) {
   if (side != FS_UPSTREAM && side != FS_DOWNSTREAM) return fail("fs_batch_set_host_rows: side must be FS_UPSTREAM or FS_DOWNSTREAM");
   if (!b->have_bc[side] || b->bc_kind[side] != FS_BC_HOST_ROW) return fail("fs_batch_set_host_rows: this side is not an FS_BC_HOST_ROW boundary");
   FS_ON_DEVICE(b);
-  return upload(b, &b->bc_params[side], rows, (size_t)3 * b->d.n_reaches);
+  const size_t B = b->d.n_reaches;
+  if (!b->kinds_per_reach[side]) return upload(b, &b->bc_params[side], rows, 3 * B);
+  // per-reach kinds: entries of reaches whose boundary the device evaluates are ignored
+  if (upload(b, &b->rows_stage, rows, 3 * B)) return -1;
+  const dim3 grid((unsigned)((B + 255) / 256));
+  if (b->d.dtype == FS_F64)
+    hipLaunchKernelGGL((merge_host_rows<double>), grid, dim3(256), 0, b->stream, (double *)b->bc_params[side], (const double *)b->rows_stage,
+                       b->reach_kinds + (size_t)side * B, B);
+  else
+    hipLaunchKernelGGL((merge_host_rows<float>), grid, dim3(256), 0, b->stream, (float *)b->bc_params[side], (const float *)b->rows_stage,
+                       b->reach_kinds + (size_t)side * B, B);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 int fs_batch_get_boundary_iterate(fs_batch *b, double *out) {

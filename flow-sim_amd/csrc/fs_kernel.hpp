@@ -213,7 +213,7 @@ template <typename R> struct KernelArgs {
   // builds per Channel / Solver (channel.py:213-241, solver.py:34-38,53-55)
   const int32_t *reach_nodes;    // [B] or nullptr: nodes of each reach (<= N; N stays the row stride of every [B][N] array)
   const R *reach_scheme;         // [3][B] or nullptr: theta, dt, dx of each reach
-  const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE)
+  const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE, or FS_BC_HOST_ROW)
   const R *poly_tz;              // IRREGULAR: stage tables (fs_poly.hpp): breakpoints [N][KP], then intervals [P][16][N] pairs
   int32_t poly_K;                // IRREGULAR: P, intervals per node in the stage tables (0: no tables, walk the edges)
   R *kc_scratch;           // long reaches (fs_long.hpp): [B][4][passes * 64 W M] level constants, owned by the batch

@@ -119,15 +119,30 @@ class PreissmannBatch:
         A.check(self._lib.fs_batch_set_reach_scheme(self._h, *[None if a is None else _dptr(a) for a in arrs]), "set_reach_scheme")
 
     def set_boundary_per_reach(self, side: int, specs):
-        """one BoundarySpec per reach, kinds free to differ (the closed-form kinds, BC_FLOW_HYDROGRAPH .. BC_STORAGE);
-        a spec's target is [n_levels] (sampled at that reach's own k * dt)"""
+        """one BoundarySpec per reach, kinds free to differ: the closed-form kinds BC_FLOW_HYDROGRAPH .. BC_STORAGE and, in table /
+        polyline batches, BC_STORAGE_CURVE (a general reservoir behind some of the channels, each with its own scalars and an area
+        curve of its own length) and BC_HOST_ROW on the reaches whose plugin has no device form (such a batch advances with
+        iterate(), and set_host_rows() writes the rows of those reaches only); a spec's target is [n_levels] (sampled at that
+        reach's own k * dt)"""
         assert len(specs) == self.B
         kinds = np.array([s.kind for s in specs], dtype=np.int32)
-        p = np.zeros((A.BC_MAX_PARAMS, self.B), dtype=np.float64)
+        curves = {r: np.asarray(s.params.get("curve", np.empty((0, 2))), dtype=np.float64).reshape(-1, 2)
+                  for r, s in enumerate(specs) if s.kind == A.BC_STORAGE_CURVE}
+        rows = max([A.BC_MAX_PARAMS] + [len(A.SC_NAMES) + 2 * len(c) for c in curves.values()])
+        p = np.zeros((rows, self.B), dtype=np.float64)
         tgt = None
         for r, s in enumerate(specs):
-            for i, name in enumerate(_KIND_PARAMS[s.kind]):
-                p[i, r] = float(s.params[name])
+            if s.kind == A.BC_STORAGE_CURVE:       # the FS_SC_* scalars (missing ones 0, alpha 1), then stages, then areas
+                sc = {"alpha": 1.0}
+                sc.update({k: v for k, v in s.params.items() if k != "curve"})
+                sc["n_curve"] = float(len(curves[r]))
+                nf, nc = len(A.SC_NAMES), len(curves[r])
+                p[:nf, r] = [float(sc.get(k) or 0.0) for k in A.SC_NAMES]
+                p[nf:nf + nc, r] = curves[r][:, 0]
+                p[nf + nc:nf + 2 * nc, r] = curves[r][:, 1]
+            else:
+                for i, name in enumerate(_KIND_PARAMS.get(s.kind, ())):
+                    p[i, r] = float(s.params[name])
             if s.target is not None:
                 if tgt is None:
                     tgt = np.zeros((self.L, self.B), dtype=np.float64)
@@ -135,8 +150,8 @@ class PreissmannBatch:
                 n = min(self.L, t.shape[0])
                 tgt[:n, r] = t[:n]
                 tgt[n:, r] = t[n - 1]
-        A.check(self._lib.fs_batch_set_bc_per_reach(self._h, side, kinds.ctypes.data_as(A._I), _dptr(p),
-                                                    _dptr(tgt) if tgt is not None else None), "set_boundary_per_reach")
+        A.check(self._lib.fs_batch_set_bc_per_reach_wide(self._h, side, kinds.ctypes.data_as(A._I), _dptr(p), rows,
+                                                         _dptr(tgt) if tgt is not None else None), "set_boundary_per_reach")
 
     def set_geometry_irregular(self, geo: dict, n_main_override: Optional[Sequence[float]] = None):
         """geo: the TABLE rows plus irr_x / irr_z [N, P] (rows padded beyond irr_npts), irr_npts [N]
@@ -235,7 +250,8 @@ class PreissmannBatch:
         return n.value
 
     def set_host_rows(self, side: int, dh, dq, res):
-        """Boundary row (d/dh, d/dQ, residual) of every reach at the current Newton vector (BC_HOST_ROW sides)."""
+        """Boundary row (d/dh, d/dQ, residual) of every reach at the current Newton vector (BC_HOST_ROW sides; with per-reach
+        kinds the entries of the reaches whose boundary the device evaluates are ignored)."""
         rows = np.empty((3, self.B), dtype=np.float64)
         rows[0], rows[1], rows[2] = dh, dq, res
         A.check(self._lib.fs_batch_set_host_rows(self._h, side, _dptr(rows)), "set_host_rows")

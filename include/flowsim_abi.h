@@ -194,11 +194,16 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
  *                                              rest with the last node's values -, history); entries beyond are left untouched;
  *   fs_batch_set_reach_scheme                  theta[B], dt[B], dx[B] (any may be NULL: the batch-wide value of
  *                                              fs_batch_set_scheme, which is called first); tolerance and max_iter stay batch-wide;
- *   fs_batch_set_bc_per_reach                  kinds[B] (FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE), params[FS_BC_MAX_PARAMS][B] (row i
- *                                              = parameter i of the reach's own kind, unused rows ignored), target[max_levels][B].
+ *   fs_batch_set_bc_per_reach                  kinds[B] (FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE, and FS_BC_HOST_ROW on the reaches whose
+ *                                              plugin has no device form), params[FS_BC_MAX_PARAMS][B] (row i = parameter i of the
+ *                                              reach's own kind, unused rows ignored), target[max_levels][B];
+ *   fs_batch_set_bc_per_reach_wide             the same with params[n_params][B], n_params >= FS_BC_MAX_PARAMS: room for reaches of kind
+ *                                              FS_BC_STORAGE_CURVE (a general reservoir behind some channels of the batch, each with
+ *                                              its FS_SC_* rows and an area curve of its own length: FS_SC_NFIXED + 2*n_curve <= n_params).
  * Time level k of reach r is t = k * dt[r]: targets are sampled per reach.  These batches run on the general kernels (run-time
- * boundary switch, ragged node counts); the kinds FS_BC_STORAGE_CURVE / FS_BC_HOST_ROW stay batch-wide as KINDS (fs_batch_set_bc) - a batch of
- * general reservoirs may still give every reach its own (per_reach = 1 there: scalars, area curve, outflow curve). */
+ * boundary switch, ragged node counts).  One FS_BC_HOST_ROW reach makes the batch one that advances with fs_batch_iterate (TABLE /
+ * IRREGULAR section modes): the reference runs a RatingCurve subclass on one channel next to closed-form boundaries on the others
+ * (boundary.py:56-141 is per Boundary object), and so does a batch. */
 int fs_batch_set_geometry_table_per_reach(fs_batch *b, const double *tables, const double *n_main_override);
 int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables, const int32_t *n_pts, int32_t max_pts,
                                               const double *x, const double *z, const double *limits,
@@ -206,6 +211,8 @@ int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables,
 int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes);
 int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx);
 int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target);
+int fs_batch_set_bc_per_reach_wide(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, int32_t n_params,
+                                   const double *target);
 
 /* one boundary (Boundary.__init__, boundary.py:10-46).  params[n_params] when per_reach == 0,
  * params[n_params][B] otherwise.  target[max_levels][B] (value at t = level*dt, i.e.
@@ -235,7 +242,8 @@ int32_t fs_batch_level(const fs_batch *b);   /* current time level k */
  * IRREGULAR batch (device-evaluated kinds included). */
 int fs_batch_iterate(fs_batch *b, int32_t *n_open);
 /* rows[3][B] = (d/dh, d/dQ, residual) of the side's boundary equation at the current Newton vector
- * (Boundary.df_dh, df_dQ, condition_residual: boundary.py:143-242, :56-141) */
+ * (Boundary.df_dh, df_dQ, condition_residual: boundary.py:143-242, :56-141).  On a side with per-reach kinds the entries of the
+ * reaches whose kind the device evaluates are ignored (their parameters stay). */
 int fs_batch_set_host_rows(fs_batch *b, int32_t side, const double *rows);
 /* the current Newton vector at the two boundary nodes, out[4][B] = h[0], Q[0], h[N-1], Q[N-1]
  * (what preissmann.py:200-218, :303-320 pass to the boundary: depth_at / flow_at of the iterate) */

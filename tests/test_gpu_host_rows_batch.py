@@ -71,6 +71,49 @@ def test_a_batch_of_host_evaluated_boundaries_follows_the_device_kind():
         np.testing.assert_allclose(Q_h[i, :p.N], Q_d[i, :p.N], rtol=1e-11, atol=1e-10)
 
 
+def run_mixed(ps, host):
+    """the reaches in `host` bring their downstream row from the host, the others keep the device's rating curve - one batch"""
+    from fixture_batch import boundary_spec, hetero_batch_from_problems
+    from flowsim_amd import BoundarySpec, _abi as A
+    a = np.array([p.ds.rc["a"] for p in ps]); e = np.array([p.ds.rc["b"] for p in ps])
+    with hetero_batch_from_problems(ps, mode="table", history=False) as b:
+        b.set_boundary_per_reach(A.DOWNSTREAM, [BoundarySpec(A.BC_HOST_ROW) if r in host else boundary_spec(p.ds, p.nt) for r, p in enumerate(ps)])
+        if host:
+            with pytest.raises(RuntimeError, match="fs_batch_iterate"):      # one plugin reach: the batch advances iteration by iteration
+                b.step(1)
+        poison = np.where(np.isin(np.arange(len(ps)), sorted(host)), 0.0, np.nan)      # what is handed in for the device's reaches is not looked at
+        for k in range(1, ps[0].nt):
+            while True:
+                it = b.boundary_iterate()
+                stage = it[2] + 0.0
+                res = it[3] - a * stage ** e
+                if host:
+                    b.set_host_rows(A.DOWNSTREAM, -a * e * stage ** (e - 1.0) + poison, np.ones(len(ps)) + poison, res + poison)
+                if b.iterate() == 0:
+                    break
+        assert np.all(b.status() == 0) and b.level == ps[0].nt - 1
+        return b.hydrographs(0, ps[0].nt), b.iterations(0, ps[0].nt), b.state()
+
+
+def test_host_rows_on_some_reaches_of_a_batch_only():
+    """FS_BC_HOST_ROW as a PER-REACH kind (fs_batch_set_bc_per_reach): the reference runs a RatingCurve subclass on one channel
+    and closed-form boundaries on the next (boundary.py:56-141 belongs to the Boundary object); a batch now does the same.  Every
+    third reach keeps the device kind; its results are those of the all-device batch advanced the same way bit for bit (its
+    parameters are not touched by fs_batch_set_host_rows, whatever the caller's array holds there), the others follow to rounding
+    with the same counts."""
+    ps = problems(48, seed=23)
+    host = {r for r in range(len(ps)) if r % 3}
+    hyd_d, its_d, (h_d, Q_d) = run_mixed(ps, set())
+    hyd_m, its_m, (h_m, Q_m) = run_mixed(ps, host)
+    assert np.array_equal(its_d, its_m) and np.array_equal(its_d, run_device(ps)[1])
+    for r, p in enumerate(ps):
+        if r in host:
+            np.testing.assert_allclose(hyd_m[:, :, r], hyd_d[:, :, r], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(h_m[r, :p.N], h_d[r, :p.N], rtol=1e-11)
+        else:
+            assert np.array_equal(hyd_m[:, :, r], hyd_d[:, :, r]) and np.array_equal(h_m[r, :p.N], h_d[r, :p.N]) and np.array_equal(Q_m[r, :p.N], Q_d[r, :p.N])
+
+
 def test_the_ends_come_back_as_they_are_on_the_device():
     """fs_batch_get_boundary_iterate against the full Newton vector (fs_batch_get_guess), ragged reaches, fp64"""
     from fixture_batch import hetero_batch_from_problems

@@ -227,6 +227,43 @@ def test_one_general_reservoir_per_reach():
             assert rel(stages[1:, r], fx["storage_stage"][:, 1], 1e-3) <= TOL, names[r]
 
 
+def test_general_reservoirs_behind_some_reaches_of_a_batch():
+    """FS_BC_STORAGE_CURVE as a PER-REACH kind next to the closed-form ones (fs_batch_set_bc_per_reach_wide): ten reference fixtures
+    as ONE batch - three general reservoirs with area curves of different lengths (one with none), a rating curve, stage
+    hydrographs, a fixed depth, normal depth on a compound channel; boundary kinds that differ at both ends, 17 ... 41 nodes,
+    five (theta, dt, dx) triples, 31 ... 49 levels.  Each reach against its fixture: 1e-8, identical Newton counts, reservoir stages."""
+    from fixture_batch import boundary_spec, hetero_batch_from_problems
+    from flowsim_amd import _abi as A
+    names = ("storage_curve_poly_losses", "bc_trap_poly", "storage_curve_closed", "bc_compound_normal", "bc_stage_fixed",
+             "storage_curve_power_trap", "bc_us_fixed_ds_flow", "bc_us_normal_ds_stage", "bc_us_rating_ds_stage", "storage_curve_poly_losses")
+    fxs = [O.load_fixture(os.path.join(GOLDEN, n + ".npz")) for n in names]
+    probs = [O.problem_from_fixture(fx, meta) for fx, meta in fxs]
+    # the fixtures' area curves all have 61 points: one gets two more beyond its last stage, at the last area - np.interp clamps there
+    # (lumped_storage.py:152-157), so the reservoir is the same one and the rows of the batch now differ in length
+    c = np.asarray(probs[5].ds.storage["curve"], dtype=np.float64)
+    probs[5].ds.storage["curve"] = np.concatenate([c, [[c[-1, 0] + 10.0, c[-1, 1]], [c[-1, 0] + 25.0, c[-1, 1]]]])
+    kinds = [boundary_spec(p.ds, p.nt).kind for p in probs]
+    curves = [len(boundary_spec(p.ds, p.nt).params.get("curve", ())) for p, k in zip(probs, kinds) if k == A.BC_STORAGE_CURVE]
+    assert kinds.count(A.BC_STORAGE_CURVE) == 4 and len(set(kinds)) >= 5 and len(set(curves)) >= 2, (kinds, curves)
+    assert len({p.N for p in probs}) >= 4 and len({(p.theta, p.dt, p.dx) for p in probs}) >= 5
+    L = max(p.nt for p in probs)
+    with hetero_batch_from_problems(probs, mode="table", history=True) as b:
+        # level by level: a reach whose fixture has ended goes on with its last target (its rows beyond are not looked at)
+        b.step(L - 1)
+        st = b.status()
+        h, Q = b.history_arrays(0, L)
+        its = b.iterations(0, L)
+        stages = b.storage_stages(0, L)
+        e = A.kernel_table()[b.kernel_index()]
+        assert e["boundary_class"] == -1
+    for r, ((fx, meta), p) in enumerate(zip(fxs, probs)):
+        assert st[r] == 0 or p.nt < L, (names[r], st[r])
+        assert rel(h[:p.nt, r, :p.N], fx["depth"], 1e-3) <= TOL and rel(Q[:p.nt, r, :p.N], fx["flow"], 1.0) <= TOL, names[r]
+        assert np.array_equal(its[:p.nt, r], fx["iters"]), names[r]
+        if "storage_stage" in fx.files:
+            assert rel(stages[1:p.nt, r], fx["storage_stage"][:, 1], 1e-3) <= TOL, names[r]
+
+
 def test_a_team_that_misses_a_member_gives_the_reach_up_instead_of_spinning_on(monkeypatch):
     """The exit condition of the team kernel's wait.  FS_TEAM_TEST_DROP=1 launches one workgroup too few: the last reach's team (two members
     at 8 192 nodes) waits for a member that never starts.  After about eight seconds of polling the waiting member ends its reach with
