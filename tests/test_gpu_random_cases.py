@@ -35,10 +35,12 @@ def wave(nt, dt, rise, fall, amp):
     return np.array([akbari_shape(1.0, amp, rise, fall, k * dt) for k in range(nt)])
 
 
-def random_problem(seed):
+def random_problem(seed, nodes=None):
     from synth import normal_depth_rect, normal_depth_trap
     rng = np.random.default_rng(770000 + seed)
     N = int(rng.choice([2, 3, 5, 17, 63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 400, 511, 512, 513, 700]))
+    if nodes is not None:
+        N = int(nodes)             # (the long-reach sweep below: the same draws on a reach of its own length)
     trapezoid = bool(rng.integers(0, 2))
     b = float(np.exp(rng.uniform(np.log(3.0), np.log(600.0))))
     m = float(rng.uniform(0.5, 3.0)) if trapezoid else 0.0
@@ -219,6 +221,53 @@ def test_random_reach_against_the_oracle(seed):
     _unflagged_froude.append(info["froude"])
     assert eh <= TOL and eq <= TOL, (eh, eq, info)
     assert np.array_equal(its, ref["iters"]), (its, ref["iters"], info)
+
+
+N_LONG = int(os.environ.get("FS_SWEEP_LONG", 20))
+_long_kernels = []
+
+
+@pytest.mark.parametrize("seed", range(N_LONG))
+def test_random_long_reach_against_the_oracle(seed, monkeypatch):
+    """The same draws on reaches LONGER than one lane grid (4 097 ... 32 768 nodes: Courant numbers, slopes, boundary pairs and flood
+    waves as above), on both kernels that take them: the team of workgroups (uniform sections; fs_kernel.hpp, TEAM) and the
+    multi-pass kernel (FS_NO_TEAM=1, and the table mode; fs_long.hpp).  Node counts on and off the lane-grid multiples - a last
+    member with one row, a full team, a ragged tail."""
+    from fixture_batch import batch_from_problems
+    from flowsim_amd import _abi as A
+    from oracle import c_oracle as CO
+    rng = np.random.default_rng(660000 + seed)
+    special = (4097, 8192, 8193, 12288, 16384, 16385, 32768, 32767)
+    N = special[seed] if seed < len(special) else int(rng.integers(4098, 24000))
+    p, info = random_problem(5000 + seed, nodes=N)
+    ref = CO.run(p)
+    if ref["status"] != 0 or not np.all(np.isfinite(ref["depth"])) or np.min(ref["depth"]) <= 1e-3 * info["hn"]:
+        pytest.skip(f"the oracle does not get through this draw (status {ref['status']}): {info}")
+    d, f = ref["depth"], ref["flow"]
+    uniform = "trap_uniform" if info["trapezoid"] else "rect_uniform"
+    runs = [(uniform, False), (uniform, True)] if info["ds"] != "blend" else []
+    if N <= 16384:
+        runs.append(("table", False))
+    for mode, no_team in runs:
+        if no_team:
+            monkeypatch.setenv("FS_NO_TEAM", "1")
+        else:
+            monkeypatch.delenv("FS_NO_TEAM", raising=False)
+        with batch_from_problems([p], mode=mode, history=True) as b:
+            b.step(p.nt - 1)
+            st = int(b.status()[0])
+            e = A.kernel_table()[b.kernel_index()]
+            assert st in (0, ILL), (st, mode, no_team, info)
+            assert (e["team"], e["long_reach"]) == ((1, 0) if (mode != "table" and not no_team) else (0, 1)), (e, mode, no_team)
+            _long_kernels.append((e["team"], e["long_reach"]))
+            h, Q = b.history_arrays(0, p.nt)
+            its = b.iterations(0, p.nt)[:, 0]
+        eh, eq = rel_err(h[:, 0], d, 1e-3 * info["hn"]), rel_err(Q[:, 0], f, 1e-3 * info["Qb"])
+        if st == ILL:
+            assert eh <= FLAGGED_TOL and eq <= FLAGGED_TOL, ("flagged draw off by more than 1e-2", eh, eq, mode, no_team, info)
+            continue
+        assert eh <= TOL and eq <= TOL, (eh, eq, mode, no_team, info)
+        assert np.array_equal(its, ref["iters"]), (its, ref["iters"], mode, no_team, info)
 
 
 def test_the_monitor_flags_few_draws_and_no_subcritical_prismatic_one():
