@@ -508,6 +508,9 @@ template <typename R> struct LocalElim { Parked<R> R1, R2, R3, qc; };
 // Minimum number of waves per SIMD a kernel is compiled for: caps its registers at 512 / n.  One wave per SIMD cannot
 // hide the latency of the in-wave tree, a second one is worth 20-80 % wherever the kernel fits 256 registers or nearly
 // does; forcing it on the larger kernels sends them to scratch (measured 0.25-0.8x).
+#ifndef FS_W1_LANES
+#define FS_W1_LANES 1      // one-wave fp64 kernels: the root segment and the upstream row meet through v_readlane instead of an LDS round trip (C5 fp64 +5.5 %, polyline ensemble +2.8 %, C4 +1.9 %; fp32: -0.5 %, left as it was)
+#endif
 #ifndef FS_TEAM_WPE
 #define FS_TEAM_WPE 2      // team kernels with <= 8 rows per lane: two workgroups per CU (one computes while the other waits for its team)
 #endif
@@ -891,6 +894,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       seg.u1 = R(0); seg.u3 = R(-1); seg.ru = R(0);
       R upU1 = R(0), upU3 = R(0), upRu = R(0);    // the lane's finished up row, kept for the way back
       R rcLast = R(0);                            // rc of the lane's last row (links node M: p_M = rc - m_{M-1})
+      constexpr bool kW1Lanes = FS_W1_LANES && W == 1 && !kTeam && sizeof(R) == 8;
+      R xb0 = R(0), xb1 = R(0), xb2 = R(0);      // kW1Lanes: the upstream row, valid in lane 0
       {
         NodeTerms<R> L = terms_at(0, h[0], Q[0]);
         NodeTerms<R> Rlast;
@@ -911,6 +916,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
             R *q = a.team_mail + (((size_t)reach * 2 + parity) * (G * W + 1) + G * W) * kTeamWords;
             team_put(q + 0, x + y); team_put(q + 1, x - y); team_put(q + 2, -Urow.res);
             }
+          } else if constexpr (kW1Lanes) {
+            xb0 = x + y; xb1 = x - y; xb2 = -Urow.res;
           } else {
           sm.xbc[parity][0] = x + y; sm.xbc[parity][1] = x - y; sm.xbc[parity][2] = -Urow.res;
           }
@@ -1052,6 +1059,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
         }
         team_posted();
         }
+      } else if constexpr (kW1Lanes) {
+        // nothing to post: the root segment is read from lane 63 below
       } else
       if (lane == 63) {
         R *p = sm.xseg[parity][wave];
@@ -1226,6 +1235,15 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
         if constexpr (kMonitor) { if (sm.xwarn != 0) grow = true; }
         if (sm.xflagT != 0) status = sm.xflagT;
         if (sm.xstall != 0) status = FS_TEAM_STALL;
+      } else if constexpr (kW1Lanes) {
+        // One wave: the root segment sits in lane 63, the upstream row in lane 0.  Lane 63 closes the system on its own registers (every
+        // lane executes it, lane 63's result is the one read) - the arithmetic of the general path below, without its LDS round trip.
+        tot = nrm2;                                    // (wave_sum left the total in every lane)
+        const R aU = read_lane(xb0, 0), bU = read_lane(xb1, 0), rU = read_lane(xb2, 0);
+        R p0, m0, ml;
+        close_root(seg, aU, bU, rU, p0, m0, ml);
+        pL = read_lane(p0, 63); mR = read_lane(ml, 63);
+        if constexpr (kMonitor) { if (__builtin_amdgcn_readlane(gi, 63) > growth_limit_bits<R>()) grow = true; }
       } else if constexpr (W > 1 && W >= FS_XLANES_MINW) {
         // A second, small tree over the W wave segments, one segment per LANE: lane w of every wave takes the segment of
         // wave w and the W - 1 merges run as log2 W DPP levels (row_shr:1/2/4) exactly like the in-wave tree - the same
