@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       if constexpr (kPre >= 3) pre3 = load_rec_early(std::integral_constant<int, 3>{});
       // (the tagged team form could do without this barrier - wave 0 polls the mailbox for every wave's post, its own workgroup's included - and is
       // 6 % SLOWER without it: a wave 0 that starts polling while its neighbours still fold takes their issue slots and their memory path)
+      // (one-wave reaches: no s_barrier is emitted for 64 threads, and dropping the workgroup fence with it changes nothing - measured, C4 / C5 / polylines +-0.3 %)
       __syncthreads();
       FS_T(3);
       // rc of the lane's rows for the back-substitution (step 5) does not depend on the solve: computed here, its instructions
