@@ -52,15 +52,26 @@ __device__ __forceinline__ float frcp(float x) {
 #endif
 }
 
-// 1/sqrt(x): v_rsq_f64 seed + two Newton steps (r += r/2 (1 - x r^2))
+// 1/sqrt(x): v_rsq_f64 seed r (single-precision accurate, e = 1 - x r^2 ~ 1e-7) and ONE third-order correction
+// r (1 - e)^(-1/2) = r (1 + e/2 + 3 e^2/8 + O(e^3)): the neglected term is below double rounding, five instructions where two Newton
+// steps (r += r/2 (1 - x r^2), FS_RSQ_THIRD=0) take eight
+#ifndef FS_RSQ_THIRD
+#define FS_RSQ_THIRD 1
+#endif
 __device__ __forceinline__ double frsq(double x) {
   double r = __builtin_amdgcn_rsq(x);
+#if FS_RSQ_THIRD
+  const double e = __builtin_fma(-(x * r), r, 1.0);
+  const double p = __builtin_fma(e, 0.375, 0.5);
+  return __builtin_fma(r * e, p, r);
+#else
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const double e = __builtin_fma(-(x * r), r, 1.0);
     r = __builtin_fma(r * 0.5, e, r);
   }
   return r;
+#endif
 }
 __device__ __forceinline__ float frsq(float x) {
   float r = __builtin_amdgcn_rsqf(x);
