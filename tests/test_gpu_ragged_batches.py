@@ -264,6 +264,40 @@ def test_general_reservoirs_behind_some_reaches_of_a_batch():
             assert rel(stages[1:p.nt, r], fx["storage_stage"][:, 1], 1e-3) <= TOL, names[r]
 
 
+def test_per_reach_kinds_are_checked_reach_by_reach():
+    """fs_batch_set_bc_per_reach(_wide): what the reference raises per Boundary object (boundary.py:33, :83-87) comes back per reach"""
+    from flowsim_amd import BoundarySpec, PreissmannBatch
+    from flowsim_amd import _abi as A
+    E = A.FlowsimError
+    nd = BoundarySpec(A.BC_NORMAL_DEPTH, dict(bed_slope=1e-3, bed_level=0.0))
+    flow = BoundarySpec(A.BC_FLOW_HYDROGRAPH, {}, np.full(4, 10.0))
+    curve = np.stack([np.linspace(0.0, 10.0, 5), np.linspace(1e4, 2e4, 5)], axis=1)
+    sc = lambda c: BoundarySpec(A.BC_STORAGE_CURVE, dict(min_stage=0.0, Y_min=0.0, Y_max=10.0, bed_level=0.0, surface_area=0.0, curve=c))
+    with PreissmannBatch(3, 16, 4, section_mode="rect_uniform") as b:          # uniform sections: no kernel with the general rows
+        with pytest.raises(E, match="FS_SEC_TABLE or FS_SEC_IRREGULAR"):
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, BoundarySpec(A.BC_HOST_ROW), nd])
+        with pytest.raises(E, match="FS_SEC_TABLE or FS_SEC_IRREGULAR"):
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, nd, sc(curve)])
+    with PreissmannBatch(3, 16, 4, section_mode="table") as b:
+        with pytest.raises(E, match="downstream only"):
+            b.set_boundary_per_reach(A.UPSTREAM, [flow, sc(curve), flow])
+        with pytest.raises(E, match="must be increasing"):
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, sc(curve[::-1]), nd])
+        with pytest.raises(E, match="n_curve 0 or >= 2"):
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, sc(curve[:1]), nd])
+        with pytest.raises(E, match="Insufficient arguments"):              # a closed reservoir without an area: boundary.py:83
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, sc(np.empty((0, 2))), nd])
+        with pytest.raises(E, match="Invalid boundary condition"):          # boundary.py:33
+            b.set_boundary_per_reach(A.DOWNSTREAM, [nd, BoundarySpec(17), nd])
+        with pytest.raises(E, match="Insufficient arguments"):              # a hydrograph kind without its table: boundary.py:87
+            b.set_boundary_per_reach(A.UPSTREAM, [BoundarySpec(A.BC_FLOW_HYDROGRAPH), nd, nd])
+        b.set_boundary_per_reach(A.DOWNSTREAM, [nd, sc(curve), BoundarySpec(A.BC_HOST_ROW)])        # and the three together are accepted
+        b.set_boundary_per_reach(A.UPSTREAM, [flow, flow, flow])
+        with pytest.raises(E, match="not an FS_BC_HOST_ROW boundary"):
+            b.set_host_rows(A.UPSTREAM, np.zeros(3), np.ones(3), np.zeros(3))
+        b.set_host_rows(A.DOWNSTREAM, np.zeros(3), np.ones(3), np.zeros(3))
+
+
 def test_a_team_that_misses_a_member_gives_the_reach_up_instead_of_spinning_on(monkeypatch):
     """The exit condition of the team kernel's wait.  FS_TEAM_TEST_DROP=1 launches one workgroup too few: the last reach's team (two members
     at 8 192 nodes) waits for a member that never starts.  After about eight seconds of polling the waiting member ends its reach with
