@@ -333,7 +333,8 @@ struct fs_batch {
   int32_t *reach_nodes = nullptr;       // [B] per-reach node counts (heterogeneous batch) or nullptr
   std::vector<int32_t> reach_nodes_host;      // its host copy (empty: every reach has n_nodes): where a reach's last node is
   bool any_storage[2] = {false, false}; // some reach's boundary on this side is a storage kind (per-reach kinds: OR over the reaches)
-  void *reach_scheme = nullptr;         // [3][B] per-reach theta, dt, dx or nullptr
+  void *reach_scheme = nullptr;         // [5][B] per-reach theta, dt, dx, tolerance, max_iter or nullptr
+  std::vector<double> rs_host[5];       // what the caller set per reach (empty: the batch-wide value of fs_batch_set_scheme)
   int32_t *reach_kinds = nullptr;       // [2][B] per-reach boundary kinds or nullptr
   bool kinds_per_reach[2] = {false, false};
   bool some_host_rows[2] = {false, false};      // per-reach kinds with FS_BC_HOST_ROW among them: fs_batch_set_host_rows writes those reaches' rows only
@@ -695,11 +696,17 @@ void fs_batch_destroy(fs_batch *b) {
   delete b;
 }
 
+static int rebuild_reach_scheme(fs_batch *b);
+
 int fs_batch_set_scheme(fs_batch *b, double theta, double dt, double dx, double tolerance, int32_t max_iter) {
   if (!b) return fail("null handle");
   if (!(dt > 0) || !(dx > 0) || !(tolerance > 0) || max_iter < 1) return fail("fs_batch_set_scheme: dt, dx, tolerance > 0 and max_iter >= 1 required");
   b->theta = theta; b->dt = dt; b->dx = dx; b->tol = tolerance; b->max_iter = max_iter;
   b->have_scheme = true;
+  if (b->reach_scheme) {      // per-reach values stand; the rows the caller left to the batch take the new numbers
+    FS_ON_DEVICE(b);
+    return rebuild_reach_scheme(b);
+  }
   return 0;
 }
 
@@ -962,22 +969,45 @@ int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes) {
   return refresh_row0();
 }
 
+// the [5][B] array the kernels of boundary classes 0 and -1 read: per-reach values where the caller gave them, the batch's elsewhere
+static int rebuild_reach_scheme(fs_batch *b) {
+  const size_t B = b->d.n_reaches;
+  if (b->reach_scheme) { (void)hipFree(b->reach_scheme); b->reach_scheme = nullptr; }
+  bool any = false;
+  for (auto &v : b->rs_host) any = any || !v.empty();
+  if (!any) return 0;
+  const double wide[5] = {b->theta, b->dt, b->dx, b->tol, (double)b->max_iter};
+  std::vector<double> v(5 * B);
+  for (int i = 0; i < 5; ++i)
+    for (size_t r = 0; r < B; ++r) v[i * B + r] = b->rs_host[i].empty() ? wide[i] : b->rs_host[i][r];
+  return upload(b, &b->reach_scheme, v.data(), v.size());
+}
+
 int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx) {
   if (!b) return fail("null handle");
   FS_ON_DEVICE(b);
   const size_t B = b->d.n_reaches;
-  if (!theta && !dt && !dx) {
-    if (b->reach_scheme) { (void)hipFree(b->reach_scheme); b->reach_scheme = nullptr; }
-    return 0;
+  if ((theta || dt || dx) && !b->have_scheme)
+    return fail("fs_batch_set_reach_scheme: call fs_batch_set_scheme first (tolerance, max_iter and the values of the arrays left NULL)");
+  for (size_t r = 0; r < B; ++r)
+    if ((dt && !(dt[r] > 0)) || (dx && !(dx[r] > 0))) return fail("fs_batch_set_reach_scheme: dt and dx must be positive");
+  const double *src[3] = {theta, dt, dx};
+  for (int i = 0; i < 3; ++i) {
+    if (src[i]) b->rs_host[i].assign(src[i], src[i] + B); else b->rs_host[i].clear();
   }
-  if (!b->have_scheme) return fail("fs_batch_set_reach_scheme: call fs_batch_set_scheme first (tolerance, max_iter and the values of the arrays left NULL)");
-  std::vector<double> v(3 * B);
-  for (size_t r = 0; r < B; ++r) {
-    v[r] = theta ? theta[r] : b->theta; v[B + r] = dt ? dt[r] : b->dt; v[2 * B + r] = dx ? dx[r] : b->dx;
-    if (!(v[B + r] > 0) || !(v[2 * B + r] > 0)) return fail("fs_batch_set_reach_scheme: dt and dx must be positive");
-  }
-  if (b->reach_scheme) { (void)hipFree(b->reach_scheme); b->reach_scheme = nullptr; }
-  return upload(b, &b->reach_scheme, v.data(), v.size());
+  return rebuild_reach_scheme(b);
+}
+
+int fs_batch_set_reach_tolerance(fs_batch *b, const double *tolerance, const int32_t *max_iter) {
+  if (!b) return fail("null handle");
+  FS_ON_DEVICE(b);
+  const size_t B = b->d.n_reaches;
+  if ((tolerance || max_iter) && !b->have_scheme) return fail("fs_batch_set_reach_tolerance: call fs_batch_set_scheme first");
+  for (size_t r = 0; r < B; ++r)
+    if ((tolerance && !(tolerance[r] > 0)) || (max_iter && max_iter[r] < 1)) return fail("fs_batch_set_reach_tolerance: tolerance > 0 and max_iter >= 1 required");
+  if (tolerance) b->rs_host[3].assign(tolerance, tolerance + B); else b->rs_host[3].clear();
+  if (max_iter) b->rs_host[4].assign(max_iter, max_iter + B); else b->rs_host[4].clear();
+  return rebuild_reach_scheme(b);
 }
 
 int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target) {

@@ -212,7 +212,7 @@ template <typename R> struct KernelArgs {
   // heterogeneous batches (fs_batch_set_reach_*): each reach its own channel length, grid and scheme - what the reference
   // builds per Channel / Solver (channel.py:213-241, solver.py:34-38,53-55)
   const int32_t *reach_nodes;    // [B] or nullptr: nodes of each reach (<= N; N stays the row stride of every [B][N] array)
-  const R *reach_scheme;         // [3][B] or nullptr: theta, dt, dx of each reach
+  const R *reach_scheme;         // [5][B] or nullptr: theta, dt, dx, tolerance, max_iter of each reach
   const int32_t *reach_kinds;    // [2][B] or nullptr: boundary kind of each reach, upstream row then downstream row (kinds <= FS_BC_STORAGE, or FS_BC_HOST_ROW)
   const R *poly_tz;              // IRREGULAR: stage tables (fs_poly.hpp): breakpoints [N][KP], then intervals [P][16][N] pairs
   int32_t poly_K;                // IRREGULAR: P, intervals per node in the stage tables (0: no tables, walk the edges)
@@ -635,6 +635,10 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
   const bool own_scheme = BCK <= 0 && a.reach_scheme != nullptr;          // (the kernels compiled for one boundary pair are the benchmark shapes)
   const R th = own_scheme ? a.reach_scheme[reach] : a.theta, dt = own_scheme ? a.reach_scheme[(size_t)a.B + reach] : a.dt;
   const R dx_ = own_scheme ? a.reach_scheme[(size_t)2 * a.B + reach] : a.dx;
+  // (tolerance and iteration cap of the reach's own run(), preissmann.py:101: read where they are used, so that the kernels compiled for one
+  // boundary pair - own_scheme is false at compile time there - keep the code they had)
+  auto tol_of = [&]() __attribute__((always_inline)) -> R { if constexpr (BCK <= 0) { if (own_scheme) return a.reach_scheme[(size_t)3 * a.B + reach]; } return a.tol; };
+  auto max_iter_of = [&]() __attribute__((always_inline)) -> int { if constexpr (BCK <= 0) { if (own_scheme) return (int)a.reach_scheme[(size_t)4 * a.B + reach]; } return a.max_iter; };
   R r2dt = R(1) / (R(2) * dt);
   R cq = th / dx_;                            // theta/dx
   const R cqk = (R(1) - th) / dx_;            // (1-theta)/dx
@@ -813,6 +817,8 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       } else {
       if (kBudget && budget-- <= 0) break;
       ++it;
+      if constexpr (BCK <= 0) { if (it - 1 >= max_iter_of()) { status = FS_MAX_ITER; break; } }
+      else
       if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }     // preissmann.py:124-126
       parity ^= 1;
       bool grow = false;                        // conditioning monitor: this iteration's segments grew past the limit
@@ -1432,13 +1438,20 @@ __global__ __launch_bounds__(64 * W, (min_waves<R, SEC, M, W, BCK, TEAM>())) voi
       bool below;                                                      // ||R|| < tolerance (preissmann.py:153)
       if (DIAG || M < 8) {               // (the two-rows-per-lane kernels sit on their register cap: the branch below costs C4 19 %)
         const R err = sqrt_(tot);
+        if constexpr (BCK <= 0) below = err < tol_of(); else
         below = err < a.tol;
         if (DIAG && a.trace && gt == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
       } else {
         // without a trace to write the root is only needed when tot lies within rounding of tol^2 (the decision must be
         // the one sqrt() gives, bit for bit: Newton counts are compared with the reference's)
+        if constexpr (BCK <= 0) {
+          const R tl = tol_of();
+          const R t2 = tl * tl, band = R(16) * eps_of<R>() * t2;
+          below = tot < t2 - band ? true : (tot > t2 + band ? false : sqrt_(tot) < tl);
+        } else {      // (spelled as it always was: the benchmark kernels keep their machine code, tools/isa_digest.py)
         const R t2 = a.tol * a.tol, band = R(16) * eps_of<R>() * t2;
         below = tot < t2 - band ? true : (tot > t2 + band ? false : sqrt_(tot) < a.tol);
+        }
       }
       converged = status == FS_OK && below;
       // The warning is about the system the level's result comes from - the Jacobian at the accepted iterate.  An iterate on the

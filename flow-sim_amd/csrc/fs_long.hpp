@@ -87,6 +87,8 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
   const bool own_scheme = a.reach_scheme != nullptr;
   const R th = own_scheme ? a.reach_scheme[reach] : a.theta, dt = own_scheme ? a.reach_scheme[(size_t)a.B + reach] : a.dt;
   const R dx_ = own_scheme ? a.reach_scheme[(size_t)2 * a.B + reach] : a.dx;
+  const R tol_r = own_scheme ? a.reach_scheme[(size_t)3 * a.B + reach] : a.tol;       // the reach's own run(tolerance, max_iter)
+  const int max_it = own_scheme ? (int)a.reach_scheme[(size_t)4 * a.B + reach] : a.max_iter;
   const R r2dt = R(1) / (R(2) * dt), cq = th / dx_, cqk = (R(1) - th) / dx_, hth = R(0.5) * th, hthk = R(0.5) * (R(1) - th);
   const R g = R(kG), i2c = R(0.5) / cq, kap = r2dt * i2c, dtcq = dt * cq, hx = hth * i2c, ghth = g * hth, ghthk = g * hthk, ghdt = g * hth * dt;
 
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
     while (!converged && status == FS_OK) {
       if (kBudget && budget-- <= 0) break;
       ++it;
-      if (it - 1 >= a.max_iter) { status = FS_MAX_ITER; break; }
+      if (it - 1 >= max_it) { status = FS_MAX_ITER; break; }
       R nrm2 = R(0);
       for (int phase = 0; phase < 2; ++phase) {
         for (int p = 0; p < P; ++p) {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(64 * W, (long_min_waves<R, SEC>())) void preissmann
           if (!(tot <= finite_max<R>())) status = FS_NAN;
           const R err = sqrt_(tot);
           if (a.trace && t == 0 && it <= FS_TRACE_CAP) a.trace[((size_t)level * FS_TRACE_CAP + (it - 1)) * a.B + reach] = err;
-          converged = status == FS_OK && err < a.tol;
+          converged = status == FS_OK && err < tol_r;
           if (converged && sm.xwarn != 0) warn = true;          // (the system at the accepted iterate: see the step kernel)
         }
       }   // sweeps

@@ -57,6 +57,7 @@ SIGNATURES = {
     "fs_batch_set_geometry_irregular_per_reach": (C.c_int, [_P, _D, _I, C.c_int32, _D, _D, _D, _D]),
     "fs_batch_set_reach_nodes": (C.c_int, [_P, _I]),
     "fs_batch_set_reach_scheme": (C.c_int, [_P, _D, _D, _D]),
+    "fs_batch_set_reach_tolerance": (C.c_int, [_P, _D, _I]),
     "fs_batch_set_bc_per_reach": (C.c_int, [_P, C.c_int32, _I, _D, _D]),
     "fs_batch_set_bc_per_reach_wide": (C.c_int, [_P, C.c_int32, _I, _D, C.c_int32, _D]),
     "fs_batch_set_state": (C.c_int, [_P, _D, _D]),

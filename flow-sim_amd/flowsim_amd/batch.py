@@ -118,6 +118,14 @@ class PreissmannBatch:
         arrs = [None if v is None else np.ascontiguousarray(np.broadcast_to(np.asarray(v, dtype=np.float64), (self.B,))) for v in (theta, dt, dx)]
         A.check(self._lib.fs_batch_set_reach_scheme(self._h, *[None if a is None else _dptr(a) for a in arrs]), "set_reach_scheme")
 
+    def set_reach_tolerance(self, tolerance=None, max_iter=None):
+        """per-reach convergence tolerance and iteration cap (arrays [B]; None: the batch-wide value of set_scheme): what each
+        run(tolerance=, max_iter=) of the reference has of its own (preissmann.py:101)"""
+        tol = None if tolerance is None else np.ascontiguousarray(np.broadcast_to(np.asarray(tolerance, dtype=np.float64), (self.B,)))
+        mit = None if max_iter is None else np.ascontiguousarray(np.broadcast_to(np.asarray(max_iter, dtype=np.int32), (self.B,)))
+        A.check(self._lib.fs_batch_set_reach_tolerance(self._h, None if tol is None else _dptr(tol),
+                                                       None if mit is None else mit.ctypes.data_as(A._I)), "set_reach_tolerance")
+
     def set_boundary_per_reach(self, side: int, specs):
         """one BoundarySpec per reach, kinds free to differ: the closed-form kinds BC_FLOW_HYDROGRAPH .. BC_STORAGE and, in table /
         polyline batches, BC_STORAGE_CURVE (a general reservoir behind some of the channels, each with its own scalars and an area

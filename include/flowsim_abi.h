@@ -193,7 +193,9 @@ int fs_batch_set_geometry_irregular(fs_batch *b, const double *table, const int3
  *                                              first n_nodes[r] entries of its rows of every [B][N] array (state, tables - pad the
  *                                              rest with the last node's values -, history); entries beyond are left untouched;
  *   fs_batch_set_reach_scheme                  theta[B], dt[B], dx[B] (any may be NULL: the batch-wide value of
- *                                              fs_batch_set_scheme, which is called first); tolerance and max_iter stay batch-wide;
+ *                                              fs_batch_set_scheme, which is called first);
+ *   fs_batch_set_reach_tolerance               tolerance[B], max_iter[B] (either may be NULL: the batch-wide value): every run() of the reference
+ *                                              has its own tolerance and iteration cap (preissmann.py:101);
  *   fs_batch_set_bc_per_reach                  kinds[B] (FS_BC_FLOW_HYDROGRAPH .. FS_BC_STORAGE, and FS_BC_HOST_ROW on the reaches whose
  *                                              plugin has no device form), params[FS_BC_MAX_PARAMS][B] (row i = parameter i of the
  *                                              reach's own kind, unused rows ignored), target[max_levels][B];
@@ -210,6 +212,7 @@ int fs_batch_set_geometry_irregular_per_reach(fs_batch *b, const double *tables,
                                               const double *n_main_override);
 int fs_batch_set_reach_nodes(fs_batch *b, const int32_t *n_nodes);
 int fs_batch_set_reach_scheme(fs_batch *b, const double *theta, const double *dt, const double *dx);
+int fs_batch_set_reach_tolerance(fs_batch *b, const double *tolerance, const int32_t *max_iter);
 int fs_batch_set_bc_per_reach(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, const double *target);
 int fs_batch_set_bc_per_reach_wide(fs_batch *b, int32_t side, const int32_t *kinds, const double *params, int32_t n_params,
                                    const double *target);

@@ -111,12 +111,11 @@ def batch_from_problems(problems, mode="auto", dtype="f64", history=True, n_main
 
 
 def hetero_batch_from_problems(problems, mode="table", history=True, monitor=None):
-    """ONE batch from oracle Problems that share nothing but the tolerance: every reach its own channel (node table), node
-    count, theta / dt / dx, boundary kinds and number of levels (fs_batch_set_geometry_table_per_reach, fs_batch_set_reach_nodes,
+    """ONE batch from oracle Problems that share nothing: every reach its own channel (node table), node
+    count, theta / dt / dx, tolerance / iteration cap, boundary kinds and number of levels (fs_batch_set_geometry_table_per_reach, fs_batch_set_reach_nodes,
     fs_batch_set_reach_scheme, fs_batch_set_bc_per_reach).  Rows of shorter reaches are padded with their last node."""
     B, N, L = len(problems), max(p.N for p in problems), max(p.nt for p in problems)
     p0 = problems[0]
-    assert all(p.tol == p0.tol and p.max_iter == p0.max_iter for p in problems)
 
     def pad(a):
         a = np.asarray(a, dtype=np.float64)
@@ -126,6 +125,8 @@ def hetero_batch_from_problems(problems, mode="table", history=True, monitor=Non
     b.set_geometry_table({k: np.stack([pad(p.geo[k]) for p in problems]) for k in A.GEO_ROWS})
     b.set_reach_nodes([p.N for p in problems])
     b.set_reach_scheme([p.theta for p in problems], [p.dt for p in problems], [p.dx for p in problems])
+    if any(p.tol != p0.tol or p.max_iter != p0.max_iter for p in problems):
+        b.set_reach_tolerance([p.tol for p in problems], [p.max_iter for p in problems])
     b.set_boundary_per_reach(A.UPSTREAM, [boundary_spec(p.us, p.nt) for p in problems])
     b.set_boundary_per_reach(A.DOWNSTREAM, [boundary_spec(p.ds, p.nt) for p in problems])
     b.set_state(np.stack([pad(p.h0) for p in problems]), np.stack([pad(p.Q0) for p in problems]))

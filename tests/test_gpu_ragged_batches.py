@@ -228,14 +228,17 @@ def test_one_general_reservoir_per_reach():
 
 
 def test_general_reservoirs_behind_some_reaches_of_a_batch():
-    """FS_BC_STORAGE_CURVE as a PER-REACH kind next to the closed-form ones (fs_batch_set_bc_per_reach_wide): ten reference fixtures
-    as ONE batch - three general reservoirs with area curves of different lengths (one with none), a rating curve, stage
-    hydrographs, a fixed depth, normal depth on a compound channel; boundary kinds that differ at both ends, 17 ... 41 nodes,
-    five (theta, dt, dx) triples, 31 ... 49 levels.  Each reach against its fixture: 1e-8, identical Newton counts, reservoir stages."""
+    """FS_BC_STORAGE_CURVE as a PER-REACH kind next to the closed-form ones (fs_batch_set_bc_per_reach_wide): twelve reference fixtures
+    as ONE batch - three general reservoirs with area curves of different lengths (one with none), the constant-area reservoir of
+    cases/example (BASELINE C1), a rating curve, stage hydrographs, a fixed depth, normal depth on a compound channel and on
+    cases/akbari_firoozi (C2); boundary kinds that differ at both ends, 17 ... 41 nodes, seven (theta, dt, dx) triples, two tolerances
+    (every reach its own: fs_batch_set_reach_tolerance), 21 ... 49 levels.  Each reach against its fixture: 1e-8, identical Newton
+    counts (C1's 13 iterations of the first level among them), reservoir stages."""
     from fixture_batch import boundary_spec, hetero_batch_from_problems
     from flowsim_amd import _abi as A
     names = ("storage_curve_poly_losses", "bc_trap_poly", "storage_curve_closed", "bc_compound_normal", "bc_stage_fixed",
-             "storage_curve_power_trap", "bc_us_fixed_ds_flow", "bc_us_normal_ds_stage", "bc_us_rating_ds_stage", "storage_curve_poly_losses")
+             "storage_curve_power_trap", "bc_us_fixed_ds_flow", "bc_us_normal_ds_stage", "bc_us_rating_ds_stage", "storage_curve_poly_losses",
+             "example", "akbari")        # BASELINE configs C1 and C2: tolerance 1e-4 next to the others' 1e-6 (fs_batch_set_reach_tolerance)
     fxs = [O.load_fixture(os.path.join(GOLDEN, n + ".npz")) for n in names]
     probs = [O.problem_from_fixture(fx, meta) for fx, meta in fxs]
     # the fixtures' area curves all have 61 points: one gets two more beyond its last stage, at the last area - np.interp clamps there
@@ -245,7 +248,7 @@ def test_general_reservoirs_behind_some_reaches_of_a_batch():
     kinds = [boundary_spec(p.ds, p.nt).kind for p in probs]
     curves = [len(boundary_spec(p.ds, p.nt).params.get("curve", ())) for p, k in zip(probs, kinds) if k == A.BC_STORAGE_CURVE]
     assert kinds.count(A.BC_STORAGE_CURVE) == 4 and len(set(kinds)) >= 5 and len(set(curves)) >= 2, (kinds, curves)
-    assert len({p.N for p in probs}) >= 4 and len({(p.theta, p.dt, p.dx) for p in probs}) >= 5
+    assert len({p.N for p in probs}) >= 4 and len({(p.theta, p.dt, p.dx) for p in probs}) >= 7 and len({p.tol for p in probs}) == 2
     L = max(p.nt for p in probs)
     with hetero_batch_from_problems(probs, mode="table", history=True) as b:
         # level by level: a reach whose fixture has ended goes on with its last target (its rows beyond are not looked at)

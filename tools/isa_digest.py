@@ -31,7 +31,7 @@ def digests(obj):
         bundle, co = os.path.join(tmp, "f.bundle"), os.path.join(tmp, "f.co")
         run(f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={bundle}", obj, os.path.join(tmp, "copy.o"))
         run(f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={bundle}", f"--output={co}")
-        out, name, body = {}, None, []
+        out, name, body, pcrel = {}, None, [], 0
         for line in run(f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", co).splitlines():
             m = re.match(r"^[0-9a-f]* ?<(.+)>:$", line.strip())
             if m:
@@ -39,7 +39,15 @@ def digests(obj):
                     out[name] = body
                 name, body = m.group(1), []
             elif name and line.strip():
-                body.append(re.sub(r"\s+", " ", line.split("//")[0].strip()))
+                ins = re.sub(r"\s+", " ", line.split("//")[0].strip())
+                # the displacement of a pc-relative address (s_getpc_b64, then s_add_u32 / s_addc_u32 with a literal: the kernel's constant tables)
+                # depends on where the kernel sits in its object, i.e. on the SIZE OF ITS NEIGHBOURS: not part of the kernel's own code
+                if pcrel and ins.startswith(("s_add_u32", "s_addc_u32")):
+                    ins = re.sub(r", (0x[0-9a-f]+|-?\d+)$", ", REL", ins)
+                    pcrel -= 1
+                else:
+                    pcrel = 2 if ins.startswith("s_getpc_b64") else 0
+                body.append(ins)
         if name:
             out[name] = body
     names = run("c++filt", *out.keys()).splitlines()
