@@ -347,12 +347,22 @@ template <typename R> __device__ __forceinline__ void sec_derive(SecParams<R> &s
 
 // K_i^1.5 of one sub-section, K_i = A_i R_i^(2/3) / n_i (hydraulics.py:15-26):  A_i^2.5 / (P_i n_i^1.5) - one reciprocal
 // root and one reciprocal instead of an x^(2/3), a division by n and an x^1.5
+#ifndef FS_K15_ONE_RSQ
+#define FS_K15_ONE_RSQ 1   // A^2.5 / P = A^3 / sqrt(A P^2): one reciprocal root in place of a reciprocal root and a reciprocal
+#endif
 template <typename R> __device__ __forceinline__ R k15_(R A, R P, R n15) {
+#if FS_K15_ONE_RSQ
+  return (A > R(0) && P > R(0)) ? (A * A) * (A * frsq(A * (P * P))) * n15 : R(0);
+#else
   return (A > R(0) && P > R(0)) ? A * A * fsqrt_pos(A) * frcp(P) * n15 : R(0);
+#endif
 }
 
 #ifndef FS_GEN_RCP3
 #define FS_GEN_RCP3 1
+#endif
+#ifndef FS_GEN_RK_ALG
+#define FS_GEN_RK_ALG 1
 #endif
 template <typename R>
 __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) {
@@ -364,6 +374,7 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
   R dPdh = R(2) * s.sm;
   const bool over = s.compound && d > s.hbf;
   R K = R(0);
+  R cK = R(0);                                                     // over bank: (sum of K_i^1.5)^(-1/3)
   if (over) {
     const R dfp = d - s.hbf;
     const R hm = R(0.5) * s.mfp * dfp;
@@ -374,7 +385,13 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
     T = (s.bl + s.Tb + s.br) + R(2) * s.mfp * dfp;
     dPdh = R(2) * s.sfp;
     const R A_m = fma_(s.Tb, dfp, s.Am);                            // :694 (column included)
+#if FS_GEN_RK_ALG
+    const R S15 = k15_(A_l, P_l, s.kl15) + k15_(A_m, s.Pm, s.km15) + k15_(A_r, P_r, s.kr15);
+    cK = S15 > R(0) ? rcbrt_pos(S15) : R(0);                       // K = S^(2/3) = S S^(-1/3), 1/K = (S^(-1/3))^2
+    K = S15 * cK;                                                  // :741-754
+#else
     K = p23_(k15_(A_l, P_l, s.kl15) + k15_(A_m, s.Pm, s.km15) + k15_(A_r, P_r, s.kr15));      // :741-754
+#endif
   }
   // divisions are reciprocal (v_rcp_f64 + one Newton step, 2e-15) times multiply: an IEEE fp64 divide is ~14 instructions
 #if FS_GEN_RCP3
@@ -394,7 +411,14 @@ __device__ FS_GEN_ATTR GeneralProps<R> general_props(const SecParams<R> s, R h) 
   // in bank K = A R^(2/3) / n_main; the reference's round trip (K^1.5)^(2/3) for a compound section in bank (:747-754)
   // is the identity, and its equivalent n = A R^(2/3) / K (:710-739) is n_main there
   if (!over) K = A * R23 * s.rnm;
+#if FS_GEN_RK_ALG && FS_GEN_RCP3
+  // 1/K without a reciprocal: in bank n / (A R^(2/3)) = n (1/A) (R^(-1/3))^2, over bank the square of the sum's reciprocal cube root
+  // (0 where K is 0: a dry node has 1/A = 0, an empty sum has cK = 0)
+  const R rA_ = wet ? r3 * PT : R(0);
+  g.rK = over ? cK * cK : s.nm * rA_ * (y13 * y13);
+#else
   g.rK = K > R(0) ? frcp(K) : R(0);
+#endif
   g.neq = over ? A * R23 * g.rK : s.nm;
   g.dRdA = (P <= R(0) || T <= R(0)) ? R(0) : (P - A * (dPdh * rT)) * (rP * rP);   // :766-790
   // dK/dA = (R^(2/3) + (2/3) A R^(-1/3) dR/dA) / n_eq with the frozen n_eq = A R^(2/3) / K (:756-764), so
