@@ -414,6 +414,9 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   __device__ __forceinline__ const R *table_slot(int node) const { return ptz + (size_t)tb.N * poly_table_bp(pK) + 2 * (size_t)node; }
   __device__ __forceinline__ PolyNode<R> poly(int node) const {
     PolyNode<R> p;
+#ifdef FS_BOUNDS
+    node = (int)FS_CHK(16, node, tb.N);
+#endif
     const int N = tb.N;
     typedef const __attribute__((address_space(1))) R *GlobalR;              // (device memory: global loads, not flat ones)
     typedef const __attribute__((address_space(1))) int32_t *GlobalI;
@@ -446,6 +449,10 @@ template <typename R> struct Geometry<R, FS_SEC_IRREGULAR> {
   // fetched its own table pointer and interval from scratch ahead of every evaluation, a memory round trip in front of the one it needs.)
   __device__ __forceinline__ static int opaque(int node) { asm volatile("" : "+v"(node)); return node; }
   __device__ __forceinline__ NodeTerms<R> terms_hinted(int node, R h, R Q, int &kh, PolyBC<R> &bc) const {
+#ifdef FS_BOUNDS
+    node = (int)FS_CHK(15, node, tb.N);
+    if (kh >= 0) kh = (int)FS_CHK(14, kh, pK);
+#endif
     if (kh == -2) return node_terms_general_call(section(opaque(node)), h, Q);
     return node_terms_poly_hinted(table_slot(node), tb.N, tb.has_over, tb.n_over, kh, h, Q, bc,
                                   [&]() { return terms_scan(*this, opaque(node), h, Q); });

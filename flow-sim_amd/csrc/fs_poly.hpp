@@ -36,6 +36,17 @@ namespace fs {
 
 // vertex j of a node lives at x[j * stride], z[j * stride] (vertex-major [P][N] tables: the lanes
 // of a wave walk different nodes in step)
+// -DFS_BOUNDS (audit builds only): every index of the polyline path against its allocation; a violation is printed, the index clamped to 0
+#ifdef FS_BOUNDS
+__device__ __forceinline__ long fs_chk(int site, long idx, long lim) {
+  if (idx < 0 || idx >= lim) { printf("FS_BOUNDS site %d idx %ld lim %ld\n", site, idx, lim); return 0; }
+  return idx;
+}
+#define FS_CHK(site, idx, lim) fs_chk(site, (long)(idx), (long)(lim))
+#else
+#define FS_CHK(site, idx, lim) (idx)
+#endif
+
 template <typename R> struct PolyNode {
   const R *x, *z;
   int stride, n;
@@ -126,8 +137,8 @@ __device__ FS_POLY_ATTR PolySums<R> poly_sums_walk(const PolyNode<R> nd, const P
   const int j0 = v.lo - (v.vl ? 1 : 0), j1 = v.hi + (v.vr ? 1 : 0);
   typedef const __attribute__((address_space(1))) R *GlobalR;          // (device memory: global loads, not flat ones)
   const GlobalR gx = (GlobalR)nd.x, gz = (GlobalR)nd.z;
-  auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : gx[(size_t)j * nd.stride]); };
-  auto Z = [&](int j) { return (j < v.lo || j > v.hi) ? v.zc : gz[(size_t)j * nd.stride]; };
+  auto X = [&](int j) { return j < v.lo ? v.xl : (j > v.hi ? v.xr : gx[(size_t)FS_CHK(1, j, nd.n) * nd.stride]); };
+  auto Z = [&](int j) { return (j < v.lo || j > v.hi) ? v.zc : gz[(size_t)FS_CHK(2, j, nd.n) * nd.stride]; };
   const R xa = X(j0), xb = X(j1);             // self.x[0], self.x[-1] of this (sub-)section
   R A0 = 0, P0 = 0, T0 = 0, A1 = 0, P1 = 0, A2 = 0, P2 = 0, Td = 0;
   R Al = 0, Pl = 0, Am = 0, Pm = 0, Ar = 0, Pr = 0;
@@ -236,7 +247,7 @@ template <typename R>
 __device__ __forceinline__ void poly_load_block(const R *tco, int cstride, int k, R (&co)[FS_PT_USED]) {
   typedef R R2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(1))) R2 *GlobalR2;
-  const GlobalR2 cb = (GlobalR2)tco + (size_t)k * (FS_PT_BLOCK / 2) * cstride;
+  const GlobalR2 cb = (GlobalR2)tco + (size_t)FS_CHK(3, k, 4096) * (FS_PT_BLOCK / 2) * cstride;
 #pragma unroll
   for (int i = 0; i < FS_PT_USED / 2; ++i) { const R2 v = cb[(size_t)i * cstride]; co[2 * i] = v.x; co[2 * i + 1] = v.y; }
 }
@@ -262,7 +273,7 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, 
   for (int j0 = 0; j0 < nd.KP / 2; j0 += 8) {          // 16 breakpoints per round: all eight loads issued before the first compare
     R2 z[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) z[i] = bp[j0 + i];
+    for (int i = 0; i < 8; ++i) z[i] = bp[FS_CHK(4, j0 + i, nd.KP / 2)];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { c1 += (z[i].x < s1) + (z[i].y < s1); c2 += (z[i].x <= s2) + (z[i].y <= s2); }
   }
@@ -272,7 +283,7 @@ __device__ FS_POLY_ATTR PolyEval<R> poly_eval_whole(const PolyNode<R> nd, R hw, 
   *nsub = 0;
   if (c1 > 0) {
     R co[FS_PT_USED];
-    poly_load_block(nd.tco, nd.cstride, c1 - 1, co);
+    poly_load_block(nd.tco, nd.cstride, (int)FS_CHK(5, c1 - 1, nd.K), co);
     q = poly_sums_table(co, co[FS_PT_ZLO], hw);
     *nsub = (int)co[FS_PT_NSUB];
     if (kout) *kout = c1 - 1;
@@ -314,7 +325,7 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
     nsub = 0;
     int run = 0;
     for (int j = 0; j < nd.n; ++j) {
-      const bool wet = gz[(size_t)j * nd.stride] < hw;
+      const bool wet = gz[(size_t)FS_CHK(6, j, nd.n) * nd.stride] < hw;
       if (wet) ++run;
       if (!wet || j == nd.n - 1) { nsub += run >= 2; run = 0; }
     }
@@ -323,20 +334,20 @@ __device__ FS_POLY_ATTR NodeTerms<R> node_terms_poly(const PolyNode<R> nd, R h, 
     R Ks = 0, dKs = 0;
     int s = -1;
     for (int j = 0; j <= nd.n; ++j) {
-      const bool wet = j < nd.n && gz[(size_t)j * nd.stride] < hw;
+      const bool wet = j < nd.n && gz[(size_t)FS_CHK(7, j, nd.n) * nd.stride] < hw;
       if (wet && s < 0) s = j;
       if (!wet && s >= 0) {
         const int en = j;                                   // one past the last wet vertex
         if (en - s >= 2) {
           PolyView<R> v;
           v.lo = s; v.hi = en - 1; v.zc = hw;
-          v.vl = s > 0 && gz[(size_t)(s - 1) * nd.stride] > hw;
-          v.xl = gx[(size_t)s * nd.stride];               // :357 (np.interp, decreasing abscissa)
+          v.vl = s > 0 && gz[(size_t)FS_CHK(8, s - 1, nd.n) * nd.stride] > hw;
+          v.xl = gx[(size_t)FS_CHK(9, s, nd.n) * nd.stride];               // :357 (np.interp, decreasing abscissa)
           v.vr = false; v.xr = R(0);
           if (en < nd.n) {
-            const R za = gz[(size_t)(en - 1) * nd.stride], zb = gz[(size_t)en * nd.stride];
+            const R za = gz[(size_t)FS_CHK(10, en - 1, nd.n) * nd.stride], zb = gz[(size_t)FS_CHK(11, en, nd.n) * nd.stride];
             if (za < hw && zb > hw) {                       // :360-363
-              const R xa_ = gx[(size_t)(en - 1) * nd.stride], xb_ = gx[(size_t)en * nd.stride];
+              const R xa_ = gx[(size_t)FS_CHK(12, en - 1, nd.n) * nd.stride], xb_ = gx[(size_t)FS_CHK(13, en, nd.n) * nd.stride];
               v.vr = true;
               v.xr = (xb_ - xa_) / (zb - za) * (hw - za) + xa_;
             }
